@@ -1,0 +1,647 @@
+/* oracle/fgnn_oracle.c — CPU restatement of the reference's BP4 + feedback-GNN hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE.  It is the checker for the HIP kernels in feedback_gnn_amd/csrc
+ * and the "port" CPU baseline timed by bench.py; nothing in the product imports, links or calls it.
+ *
+ * What it restates (all paths relative to /root/reference):
+ *   sionna/fec/ldpc/decoding_q.py   QLDPCBPDecoder   (:227-275 VN update, :313-363 tanh CN,
+ *                                   :365-431 phi CN, :539-644 min-sum CN, :433-471 soft syndrome,
+ *                                   :661-797 iteration loop + hard decision)
+ *   sionna/fec/ldpc/feedback_gnn.py Feedback_GNN.call (:161-188), reduce_msg (:130-150),
+ *                                   Sandwich_BP_GNN_Evaluation_Model.call (:293-361)
+ *   sionna/fec/ldpc/gnn.py          MLP.call (:63-69)
+ *   sionna/channel/pauli.py         Pauli.call, non-wt branch (:98-108)
+ *   sionna/utils/metrics.py         count_block_errors (:194-223)
+ *
+ * Parity pinning: TensorFlow cannot be imported in the build container and the reference ships no
+ * tests, so this restatement is pinned by (tests/test_oracle_*.py)
+ *   - the exact float32 known-answer values committed in examples/n1270.ipynb cell 12
+ *     (saturated marginals 53.9496498 / 103.856247 / -45.8635445 / -95.7701416),
+ *   - an independent NumPy float32/float64 restatement (oracle/numpy_ref.py) that uses NumPy's own
+ *     exp/log, agreeing to <=1e-4 on converged samples,
+ *   - the reference's published BLER tables (statistical bands), and
+ *   - golden fixtures produced by executing the reference's NumPy-only code (tests/golden/).
+ * Transcendental ulp behaviour of TensorFlow itself is otherwise UNPINNED ("parity unpinned" for
+ * the op-level bits).
+ *
+ * Arithmetic: float32 throughout, elementary functions from feedback_gnn_amd/csrc/fgnn_math.h
+ * (pure fma/add/mul, shared with the GPU kernels so both produce identical bits), sums in the
+ * canonical order "ascending neighbour index" (SURVEY.md Appendix A.7).
+ *
+ * Build: gcc -O2 -ffp-contract=off -mfma -fopenmp -shared -fPIC (oracle/Makefile).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../feedback_gnn_amd/csrc/fgnn_math.h"
+#include "../feedback_gnn_amd/csrc/fgnn_rng.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+enum { OG_CN_TANH = 0, OG_CN_PHI = 1, OG_CN_MINSUM = 2 };
+
+typedef struct {
+    int rows, nnz;
+    int* ptr; /* [rows+1] */
+    int* col; /* [nnz] ascending within a row */
+} og_csr;
+
+typedef struct og_graph {
+    int n, m[2], E[2];
+    /* side 0 = hx, side 1 = hz.  Canonical (VN-major) edge order: sorted by (qubit, check). */
+    int* vptr[2];  /* [n+1]           */
+    int* vchk[2];  /* [E]  check id of each VN-major edge */
+    int* cptr[2];  /* [m+1]           */
+    int* cslot[2]; /* [E]  VN-major slot of the k-th edge of a check (ascending qubit) */
+    int* cvn[2];   /* [E]  qubit id of that edge */
+    og_csr logit_rows[2]; /* pcm_x_perp, pcm_z_perp of QLDPCBPDecoder (decoding_q.py:33-37) */
+    og_csr perp[2];       /* hx_perp, hz_perp for the residual check (feedback_gnn.py:352-353) */
+} og_graph;
+
+static void csr_free(og_csr* c)
+{
+    free(c->ptr);
+    free(c->col);
+    memset(c, 0, sizeof(*c));
+}
+
+/* COO (row, col) -> CSR with ascending columns (counting sort by row, insertion sort within row). */
+static void csr_from_coo(og_csr* out, int rows, int nnz, const int32_t* r, const int32_t* c)
+{
+    csr_free(out);
+    out->rows = rows;
+    out->nnz = nnz;
+    out->ptr = (int*)calloc((size_t)rows + 1, sizeof(int));
+    out->col = (int*)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+    for (int i = 0; i < nnz; ++i) out->ptr[r[i] + 1]++;
+    for (int i = 0; i < rows; ++i) out->ptr[i + 1] += out->ptr[i];
+    int* fill = (int*)calloc((size_t)rows + 1, sizeof(int));
+    for (int i = 0; i < nnz; ++i) {
+        int row = r[i], pos = out->ptr[row] + fill[row]++;
+        int j = pos;
+        while (j > out->ptr[row] && out->col[j - 1] > c[i]) { out->col[j] = out->col[j - 1]; --j; }
+        out->col[j] = c[i];
+    }
+    free(fill);
+}
+
+og_graph* og_graph_create(int n, int m_x, int m_z, int E_x, const int32_t* chk_x, const int32_t* var_x, int E_z,
+                          const int32_t* chk_z, const int32_t* var_z)
+{
+    og_graph* g = (og_graph*)calloc(1, sizeof(og_graph));
+    g->n = n;
+    g->m[0] = m_x;
+    g->m[1] = m_z;
+    g->E[0] = E_x;
+    g->E[1] = E_z;
+    const int32_t* chk[2] = {chk_x, chk_z};
+    const int32_t* var[2] = {var_x, var_z};
+    for (int s = 0; s < 2; ++s) {
+        og_csr byvn = {0}, bycn = {0};
+        csr_from_coo(&byvn, n, g->E[s], var[s], chk[s]);  /* rows = qubits, cols = checks ascending */
+        csr_from_coo(&bycn, g->m[s], g->E[s], chk[s], var[s]);
+        g->vptr[s] = byvn.ptr;
+        g->vchk[s] = byvn.col;
+        g->cptr[s] = bycn.ptr;
+        g->cvn[s] = bycn.col;
+        g->cslot[s] = (int*)malloc(sizeof(int) * (size_t)(g->E[s] > 0 ? g->E[s] : 1));
+        for (int c = 0; c < g->m[s]; ++c)
+            for (int j = bycn.ptr[c]; j < bycn.ptr[c + 1]; ++j) {
+                int v = bycn.col[j], slot = -1;
+                for (int e = byvn.ptr[v]; e < byvn.ptr[v + 1]; ++e)
+                    if (byvn.col[e] == c) { slot = e; break; }
+                g->cslot[s][j] = slot;
+            }
+    }
+    return g;
+}
+
+/* which: 0 = pcm_x_perp (x_logit rows), 1 = pcm_z_perp (z_logit rows), 2 = hx_perp, 3 = hz_perp */
+void og_graph_set_rows(og_graph* g, int which, int rows, int nnz, const int32_t* r, const int32_t* c)
+{
+    og_csr* dst = which < 2 ? &g->logit_rows[which] : &g->perp[which - 2];
+    csr_from_coo(dst, rows, nnz, r, c);
+}
+
+void og_graph_destroy(og_graph* g)
+{
+    if (!g) return;
+    for (int s = 0; s < 2; ++s) {
+        free(g->vptr[s]);
+        free(g->vchk[s]);
+        free(g->cptr[s]);
+        free(g->cslot[s]);
+        free(g->cvn[s]);
+        csr_free(&g->logit_rows[s]);
+        csr_free(&g->perp[s]);
+    }
+    free(g);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Check-node rules.  nu[] holds the v->c messages in VN-major slots; the c->v result replaces
+ * them in place.  sigma = 1-2*syndrome (decoding_q.py:720-721).
+ * ------------------------------------------------------------------------------------------ */
+
+/* _cn_update_phi, decoding_q.py:376-431 */
+static void cn_phi(const int* slot, int deg, float* msg, int synd, float factor, float* tmp)
+{
+    int neg = synd; /* parity of negative signs, syndrome folded in (:398-399) */
+    float T = 0.0f;
+    for (int j = 0; j < deg; ++j) {
+        float v = msg[slot[j]];
+        neg ^= (v < 0.0f); /* sign(0) -> +1 (:394-396) */
+        float a = fg_phi(FG_ABS(v)); /* (:411-414) */
+        tmp[j] = a;
+        T = T + a; /* (:415) ascending qubit order */
+    }
+    for (int j = 0; j < deg; ++j) {
+        float v = msg[slot[j]];
+        float out = fg_phi(T - tmp[j]); /* (:421-429) */
+        int s = neg ^ (v < 0.0f);
+        out = s ? -out : out;
+        msg[slot[j]] = out * factor; /* (:759-760) */
+    }
+}
+
+/* _cn_update_minsum, decoding_q.py:539-644 */
+static void cn_minsum(const int* slot, int deg, float* msg, int synd, float factor, float* tmp)
+{
+    const float LARGE = 10000.0f;
+    int neg = synd;
+    float minv = 0.0f;
+    for (int j = 0; j < deg; ++j) {
+        float v = msg[slot[j]];
+        v = FG_MIN(FG_MAX(v, -20.0f), 20.0f); /* (:554-556) */
+        neg ^= (v < 0.0f);
+        float a = FG_ABS(v);
+        tmp[j] = a;
+        minv = (j == 0) ? a : FG_MIN(minv, a); /* (:587) */
+    }
+    float min2 = 0.0f, nsum = 0.0f;
+    for (int j = 0; j < deg; ++j) {
+        float d = tmp[j] - minv;           /* (:595-599) */
+        d = (d == 0.0f) ? LARGE : d;       /* (:603-605) */
+        tmp[j] = d;
+        min2 = (j == 0) ? d : FG_MIN(min2, d);
+        nsum = nsum + d;
+    }
+    min2 = min2 + minv;                         /* (:609) */
+    nsum = nsum - (2.0f * LARGE - 1.0f);        /* (:616) */
+    float sg = (nsum > 0.0f) ? 1.0f : ((nsum < 0.0f) ? -1.0f : 0.0f);
+    float dm = 0.5f * (1.0f - sg);              /* (:618) */
+    float min_e = (1.0f - dm) * minv + dm * min2; /* (:622) */
+    for (int j = 0; j < deg; ++j) {
+        float v = msg[slot[j]];
+        float out = (tmp[j] == LARGE) ? min_e : minv; /* (:626) */
+        int s = neg ^ (v < 0.0f);
+        out = s ? -out : out;                       /* (:640-642) */
+        msg[slot[j]] = out * factor;
+    }
+}
+
+/* _cn_update_tanh, decoding_q.py:313-363 */
+static void cn_tanh(const int* slot, int deg, float* msg, int synd, float factor, float* tmp)
+{
+    float P = 1.0f;
+    for (int j = 0; j < deg; ++j) {
+        float t = fg_tanh(msg[slot[j]] / 2.0f);  /* (:327-329) */
+        t = (t == 0.0f) ? 1e-12f : t;            /* (:303, :332) */
+        tmp[j] = t;
+        P = (j == 0) ? t : P * t;                /* (:334) */
+    }
+    P = P * (synd ? -1.0f : 1.0f);               /* (:335) */
+    const float clipv = 0.99999988f;             /* float32(1 - 1e-7) (:49) */
+    for (int j = 0; j < deg; ++j) {
+        float q = (1.0f / tmp[j]) * P;           /* (:344-348) msg**-1 * prod */
+        q = (FG_ABS(q) < 1e-7f) ? 0.0f : q;      /* (:308-310, :354) */
+        q = FG_MIN(FG_MAX(q, -clipv), clipv);    /* (:356-358) */
+        msg[slot[j]] = (2.0f * fg_atanh(q)) * factor; /* (:361), (:759-760) */
+    }
+}
+
+/* soft syndrome of one row: _cn_update_phi_loss, decoding_q.py:433-453 */
+static float logit_row(const int* col, int deg, const float* llr)
+{
+    int neg = 0;
+    float T = 0.0f;
+    for (int j = 0; j < deg; ++j) {
+        float v = llr[col[j]];
+        neg ^= (v < 0.0f);
+        T = T + fg_phi(FG_ABS(v));
+    }
+    float out = fg_phi(T);
+    return neg ? -out : out;
+}
+
+typedef struct {
+    float *msg[2], *tmp, *lx, *lz;
+    int maxdeg;
+} og_scratch;
+
+static int graph_maxdeg(const og_graph* g)
+{
+    int d = 1;
+    for (int s = 0; s < 2; ++s)
+        for (int c = 0; c < g->m[s]; ++c) {
+            int k = g->cptr[s][c + 1] - g->cptr[s][c];
+            if (k > d) d = k;
+        }
+    return d;
+}
+
+static void scratch_alloc(const og_graph* g, og_scratch* s)
+{
+    s->maxdeg = graph_maxdeg(g);
+    s->msg[0] = (float*)malloc(sizeof(float) * (size_t)(g->E[0] + 1));
+    s->msg[1] = (float*)malloc(sizeof(float) * (size_t)(g->E[1] + 1));
+    s->tmp = (float*)malloc(sizeof(float) * (size_t)s->maxdeg);
+    s->lx = (float*)malloc(sizeof(float) * (size_t)g->n);
+    s->lz = (float*)malloc(sizeof(float) * (size_t)g->n);
+}
+
+static void scratch_free(og_scratch* s)
+{
+    free(s->msg[0]);
+    free(s->msg[1]);
+    free(s->tmp);
+    free(s->lx);
+    free(s->lz);
+}
+
+/* One codeword of QLDPCBPDecoder.call (decoding_q.py:661-797).
+ * L = channel LLRs (x,y,z planes of length n, or NULL -> llr_const for all three),
+ * msg[s] = c->v messages, VN-major, already initialised by the caller (zeros: :726-727). */
+static void bp4_one(const og_graph* g, int cn_type, int num_iter, float factor, const float* L, float llr_const,
+                    const uint8_t* sx, const uint8_t* sz, og_scratch* sc, float* out_llr /*[3,n]*/, uint8_t* xh,
+                    uint8_t* zh, float* xlogit, float* zlogit)
+{
+    const int n = g->n;
+    float* mx = sc->msg[0];
+    float* mz = sc->msg[1];
+    const uint8_t* synd[2] = {sx, sz};
+    for (int it = 0; it <= num_iter; ++it) {
+        /* ---- _vn_update (:227-275); the last pass is sum_only (:777) ---- */
+        for (int v = 0; v < n; ++v) {
+            float Sz = 0.0f, Sx = 0.0f;
+            for (int e = g->vptr[1][v]; e < g->vptr[1][v + 1]; ++e) Sz = Sz + mz[e]; /* (:244) */
+            for (int e = g->vptr[0][v]; e < g->vptr[0][v + 1]; ++e) Sx = Sx + mx[e]; /* (:245) */
+            float lx = L ? L[v] : llr_const, ly = L ? L[n + v] : llr_const, lz = L ? L[2 * n + v] : llr_const;
+            float Y = (Sz + Sx) + ly; /* (:246) */
+            float X = Sz + lx;        /* (:247) */
+            float Z = Sx + lz;        /* (:248) */
+            if (it == num_iter) {
+                out_llr[v] = X;
+                out_llr[n + v] = Y;
+                out_llr[2 * n + v] = Z;
+                continue;
+            }
+            float numx = fg_softplus(-X); /* (:265) */
+            float numz = fg_softplus(-Z); /* (:270) */
+            for (int e = g->vptr[0][v]; e < g->vptr[0][v + 1]; ++e) {
+                float m = mx[e];
+                float Ze = Z - m, Ye = Y - m;        /* (:254-255) */
+                mx[e] = numx - fg_lse2(-Ze, -Ye);     /* (:266-268) */
+            }
+            for (int e = g->vptr[1][v]; e < g->vptr[1][v + 1]; ++e) {
+                float m = mz[e];
+                float Xe = X - m, Ye = Y - m;        /* (:256-257) */
+                mz[e] = numz - fg_lse2(-Xe, -Ye);     /* (:271-273) */
+            }
+        }
+        if (it == num_iter) break;
+        /* ---- check-node update on both Tanner graphs (:752-767) ---- */
+        for (int s = 0; s < 2; ++s)
+            for (int c = 0; c < g->m[s]; ++c) {
+                const int* slot = g->cslot[s] + g->cptr[s][c];
+                int deg = g->cptr[s][c + 1] - g->cptr[s][c];
+                int sy = synd[s][c] & 1;
+                if (cn_type == OG_CN_PHI) cn_phi(slot, deg, sc->msg[s], sy, factor, sc->tmp);
+                else if (cn_type == OG_CN_MINSUM) cn_minsum(slot, deg, sc->msg[s], sy, factor, sc->tmp);
+                else cn_tanh(slot, deg, sc->msg[s], sy, factor, sc->tmp);
+            }
+    }
+    /* ---- hard decision (:783-790): argmin([0, X, Z, Y]), first minimum wins ---- */
+    for (int v = 0; v < n; ++v) {
+        float X = out_llr[v], Y = out_llr[n + v], Z = out_llr[2 * n + v];
+        int d = 0;
+        float best = 0.0f;
+        if (X < best) { best = X; d = 1; }
+        if (Z < best) { best = Z; d = 2; }
+        if (Y < best) { best = Y; d = 3; }
+        xh[v] = (uint8_t)(d & 1);
+        zh[v] = (uint8_t)(d >> 1);
+        /* cal_logit (:455-464) */
+        sc->lz[v] = fg_softplus(-X) - fg_lse2(-Z, -Y); /* llr_z */
+        sc->lx[v] = fg_softplus(-Z) - fg_lse2(-X, -Y); /* llr_x */
+    }
+    if (xlogit)
+        for (int r = 0; r < g->logit_rows[0].rows; ++r) /* (:466,:468) */
+            xlogit[r] = logit_row(g->logit_rows[0].col + g->logit_rows[0].ptr[r],
+                                  g->logit_rows[0].ptr[r + 1] - g->logit_rows[0].ptr[r], sc->lx);
+    if (zlogit)
+        for (int r = 0; r < g->logit_rows[1].rows; ++r) /* (:467,:469) */
+            zlogit[r] = logit_row(g->logit_rows[1].col + g->logit_rows[1].ptr[r],
+                                  g->logit_rows[1].ptr[r + 1] - g->logit_rows[1].ptr[r], sc->lz);
+}
+
+/* Batched QLDPCBPDecoder.call.  All arrays are codeword-major:
+ *   llr_ch [B,3,n] (x,y,z planes) or NULL (+llr_const), synd_x [B,m_x], synd_z [B,m_z],
+ *   msg_init_x/z [B,E] optional initial c->v messages (VN-major order) — NULL = zeros (:726-727),
+ *   llr_out [B,3,n], x_hat/z_hat [B,n], x_logit [B,rows(pcm_x_perp)], z_logit [B,rows(pcm_z_perp)],
+ *   msg_out_x/z [B,E] optional final c->v messages. */
+int og_bp4_decode(const og_graph* g, int cn_type, int num_iter, float factor, const float* llr_ch, float llr_const,
+                  const uint8_t* synd_x, const uint8_t* synd_z, int B, const float* msg_init_x,
+                  const float* msg_init_z, float* llr_out, uint8_t* x_hat, uint8_t* z_hat, float* x_logit,
+                  float* z_logit, float* msg_out_x, float* msg_out_z)
+{
+    const int n = g->n;
+    const int rx = g->logit_rows[0].rows, rz = g->logit_rows[1].rows;
+#pragma omp parallel
+    {
+        og_scratch sc;
+        scratch_alloc(g, &sc);
+#pragma omp for schedule(dynamic, 4)
+        for (int b = 0; b < B; ++b) {
+            if (msg_init_x) memcpy(sc.msg[0], msg_init_x + (size_t)b * g->E[0], sizeof(float) * (size_t)g->E[0]);
+            else memset(sc.msg[0], 0, sizeof(float) * (size_t)g->E[0]);
+            if (msg_init_z) memcpy(sc.msg[1], msg_init_z + (size_t)b * g->E[1], sizeof(float) * (size_t)g->E[1]);
+            else memset(sc.msg[1], 0, sizeof(float) * (size_t)g->E[1]);
+            bp4_one(g, cn_type, num_iter, factor, llr_ch ? llr_ch + (size_t)b * 3 * n : NULL, llr_const,
+                    synd_x + (size_t)b * g->m[0], synd_z + (size_t)b * g->m[1], &sc, llr_out + (size_t)b * 3 * n,
+                    x_hat + (size_t)b * n, z_hat + (size_t)b * n, x_logit ? x_logit + (size_t)b * rx : NULL,
+                    z_logit ? z_logit + (size_t)b * rz : NULL);
+            if (msg_out_x) memcpy(msg_out_x + (size_t)b * g->E[0], sc.msg[0], sizeof(float) * (size_t)g->E[0]);
+            if (msg_out_z) memcpy(msg_out_z + (size_t)b * g->E[1], sc.msg[1], sizeof(float) * (size_t)g->E[1]);
+        }
+        scratch_free(&sc);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Feedback_GNN.call, feedback_gnn.py:161-188.  Weights in the file order of the reference's
+ * pickles (gnn.py:755-791; Keras creation order feedback_gnn.py:115-128):
+ *   w[0] W_out[40,3]  w[1] b_out[3]   w[2] Wx1[4,40]  w[3] bx1[40]  w[4] Wx2[40,20] w[5] bx2[20]
+ *   w[6] Wz1[4,40]    w[7] bz1[40]    w[8] Wz2[40,20] w[9] bz2[20]  w[10] We[43,40] w[11] be[40]
+ * Dense = matmul then bias add (gnn.py:63-69); the dot product is an fmaf chain in ascending k
+ * starting from 0 (bit-identical to v_mfma_f32_16x16x4_f32 accumulation), then + bias.
+ * ------------------------------------------------------------------------------------------ */
+#define GNN_HID 40
+#define GNN_MSG 20
+
+static void gnn_edge_side(const og_graph* g, int s, const float* gcn, const float* llr, const float* W1,
+                          const float* b1, const float* W2, const float* b2, float* mean /*[n,20]*/)
+{
+    const int n = g->n;
+    for (int v = 0; v < n; ++v) {
+        float acc[GNN_MSG];
+        for (int i = 0; i < GNN_MSG; ++i) acc[i] = 0.0f;
+        int deg = g->vptr[s][v + 1] - g->vptr[s][v];
+        for (int e = g->vptr[s][v]; e < g->vptr[s][v + 1]; ++e) { /* ascending check (:101-106) */
+            float f[4] = {gcn[g->vchk[s][e]], llr[v], llr[n + v], llr[2 * n + v]}; /* (:175-178) */
+            float h[GNN_HID];
+            for (int j = 0; j < GNN_HID; ++j) {
+                float a = 0.0f;
+                for (int k = 0; k < 4; ++k) a = FG_FMA(f[k], W1[k * GNN_HID + j], a);
+                h[j] = fg_tanh(a + b1[j]);
+            }
+            for (int i = 0; i < GNN_MSG; ++i) {
+                float a = 0.0f;
+                for (int j = 0; j < GNN_HID; ++j) a = FG_FMA(h[j], W2[j * GNN_MSG + i], a);
+                float msg = a + b2[i];
+                acc[i] = (e == g->vptr[s][v]) ? msg : acc[i] + msg; /* reduce_sum over the VN's edges */
+            }
+        }
+        for (int i = 0; i < GNN_MSG; ++i) mean[v * GNN_MSG + i] = deg > 0 ? acc[i] / (float)deg : 0.0f; /* reduce_mean (:141) */
+    }
+}
+
+static void gnn_one(const og_graph* g, const float* const* w, const float* llr /*[3,n] X,Y,Z*/,
+                    const float* logit_hx, const float* logit_hz, const uint8_t* sx, const uint8_t* sz,
+                    float* out /*[3,n]*/, float* work)
+{
+    const int n = g->n;
+    float* gx = work;                 /* [m_x] */
+    float* gz = gx + g->m[0];         /* [m_z] */
+    float* mxm = gz + g->m[1];        /* [n,20] */
+    float* mzm = mxm + (size_t)n * GNN_MSG;
+    for (int c = 0; c < g->m[0]; ++c) gx[c] = logit_hx[c] * (sx[c] ? -1.0f : 1.0f); /* (:168-171) */
+    for (int c = 0; c < g->m[1]; ++c) gz[c] = logit_hz[c] * (sz[c] ? -1.0f : 1.0f); /* (:169-172) */
+    gnn_edge_side(g, 0, gx, llr, w[2], w[3], w[4], w[5], mxm); /* vn_msg_mlp_x (:180,:183) */
+    gnn_edge_side(g, 1, gz, llr, w[6], w[7], w[8], w[9], mzm); /* vn_msg_mlp_z (:181,:184) */
+    for (int v = 0; v < n; ++v) { /* (:186) */
+        float in[43];
+        for (int i = 0; i < GNN_MSG; ++i) { in[i] = mxm[v * GNN_MSG + i]; in[GNN_MSG + i] = mzm[v * GNN_MSG + i]; }
+        in[40] = llr[v];
+        in[41] = llr[n + v];
+        in[42] = llr[2 * n + v];
+        float h[GNN_HID];
+        for (int j = 0; j < GNN_HID; ++j) {
+            float a = 0.0f;
+            for (int k = 0; k < 43; ++k) a = FG_FMA(in[k], w[10][k * GNN_HID + j], a);
+            h[j] = fg_tanh(a + w[11][j]);
+        }
+        for (int i = 0; i < 3; ++i) {
+            float a = 0.0f;
+            for (int j = 0; j < GNN_HID; ++j) a = FG_FMA(h[j], w[0][j * 3 + i], a);
+            out[i * n + v] = a + w[1][i];
+        }
+    }
+}
+
+static size_t gnn_work_floats(const og_graph* g) { return (size_t)g->m[0] + g->m[1] + 2 * (size_t)g->n * GNN_MSG; }
+
+/* llr [B,3,n] (X,Y,Z planes = h_vn), logit_hx [B,m_x], logit_hz [B,m_z], out [B,3,n]. */
+int og_feedback_gnn(const og_graph* g, const float* const* w, const float* llr, const float* logit_hx,
+                    const float* logit_hz, const uint8_t* synd_x, const uint8_t* synd_z, int B, float* out)
+{
+    const int n = g->n;
+#pragma omp parallel
+    {
+        float* work = (float*)malloc(sizeof(float) * gnn_work_floats(g));
+#pragma omp for schedule(dynamic, 4)
+        for (int b = 0; b < B; ++b)
+            gnn_one(g, w, llr + (size_t)b * 3 * n, logit_hx + (size_t)b * g->m[0], logit_hz + (size_t)b * g->m[1],
+                    synd_x + (size_t)b * g->m[0], synd_z + (size_t)b * g->m[1], out + (size_t)b * 3 * n, work);
+        free(work);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Pauli.call, pauli.py:98-108 with px=pz=2p/3, py=p/3 (feedback_gnn.py:298).
+ * tf.random.uniform is unseeded in the reference; the build defines the stream:
+ * Philox4x32-10, key = seed, counter = (sample index, word block) — see fgnn_rng.h.
+ * ------------------------------------------------------------------------------------------ */
+int og_pauli_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, uint8_t* noise_x, uint8_t* noise_z)
+{
+    fg_pauli_thr thr = fg_pauli_thresholds(p);
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int q0 = 0; q0 < n; q0 += 4) {
+            float u[4];
+            fg_uniform4(seed, first_sample + (uint64_t)b, (uint32_t)(q0 >> 2), u);
+            for (int k = 0; k < 4 && q0 + k < n; ++k) {
+                noise_x[(size_t)b * n + q0 + k] = fg_pauli_x(u[k], thr);
+                noise_z[(size_t)b * n + q0 + k] = fg_pauli_z(u[k], thr);
+            }
+        }
+    return 0;
+}
+
+/* y[b, r] = (A x[b,:]) mod 2 for a CSR binary matrix (int_mod_2(tf.matmul(...)), feedback_gnn.py:308-309). */
+static void spmv2(const int* ptr, const int* col, int rows, const uint8_t* x, uint8_t* y)
+{
+    for (int r = 0; r < rows; ++r) {
+        unsigned a = 0;
+        for (int j = ptr[r]; j < ptr[r + 1]; ++j) a ^= x[col[j]];
+        y[r] = (uint8_t)(a & 1);
+    }
+}
+
+/* syndrome_x = hx noise_z, syndrome_z = hz noise_x (feedback_gnn.py:308-309). */
+int og_syndrome(const og_graph* g, const uint8_t* ex, const uint8_t* ez, int B, uint8_t* synd_x, uint8_t* synd_z)
+{
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        spmv2(g->cptr[0], g->cvn[0], g->m[0], ez + (size_t)b * g->n, synd_x + (size_t)b * g->m[0]);
+        spmv2(g->cptr[1], g->cvn[1], g->m[1], ex + (size_t)b * g->n, synd_z + (size_t)b * g->m[1]);
+    }
+    return 0;
+}
+
+/* Residual check, feedback_gnn.py:343-361.  s_hat [B, m_z+m_x] = [hz xd ; hx zd],
+ * ls_hat [B, rows(hx_perp)+rows(hz_perp)] = [hx_perp xd ; hz_perp zd]; flags[b] bit0 = any(s_hat)
+ * ("flagged"), bit1 = any(ls_hat) ("block error"), misc.py:649-651 + metrics.py:221-223. */
+int og_residual(const og_graph* g, const uint8_t* ex, const uint8_t* ez, const uint8_t* xh, const uint8_t* zh, int B,
+                uint8_t* s_hat, uint8_t* ls_hat, uint8_t* flags)
+{
+    const int n = g->n, ms = g->m[1] + g->m[0], ml = g->perp[0].rows + g->perp[1].rows;
+#pragma omp parallel
+    {
+        uint8_t* xd = (uint8_t*)malloc((size_t)2 * n + (size_t)ms + (size_t)ml + 4);
+        uint8_t* zd = xd + n;
+        uint8_t* sl = zd + n;
+        uint8_t* ll = sl + ms;
+#pragma omp for schedule(static)
+        for (int b = 0; b < B; ++b) {
+            for (int v = 0; v < n; ++v) {
+                xd[v] = ex[(size_t)b * n + v] ^ xh[(size_t)b * n + v]; /* (:346) */
+                zd[v] = ez[(size_t)b * n + v] ^ zh[(size_t)b * n + v]; /* (:347) */
+            }
+            spmv2(g->cptr[1], g->cvn[1], g->m[1], xd, sl);              /* sx = hz xd (:349) */
+            spmv2(g->cptr[0], g->cvn[0], g->m[0], zd, sl + g->m[1]);    /* sz = hx zd (:350) */
+            spmv2(g->perp[0].ptr, g->perp[0].col, g->perp[0].rows, xd, ll);                     /* (:352) */
+            spmv2(g->perp[1].ptr, g->perp[1].col, g->perp[1].rows, zd, ll + g->perp[0].rows);  /* (:353) */
+            unsigned f = 0, l = 0;
+            for (int i = 0; i < ms; ++i) f |= sl[i];
+            for (int i = 0; i < ml; ++i) l |= ll[i];
+            if (s_hat) memcpy(s_hat + (size_t)b * ms, sl, (size_t)ms);
+            if (ls_hat) memcpy(ls_hat + (size_t)b * ml, ll, (size_t)ml);
+            if (flags) flags[b] = (uint8_t)((f & 1) | ((l & 1) << 1));
+        }
+        free(xd);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Sandwich_BP_GNN_Evaluation_Model.call, feedback_gnn.py:293-361, on given noise.
+ *   num_layers decoders (iters[i], factors[i], cn_types[i]) and num_layers-1 feedback GNNs
+ *   (weights[i-1] = 12 arrays).  llr_const = log(3(1-p0)/p0) is computed by the caller (:311-313).
+ *   x_hat/z_hat [B,n] = merged final estimates (:339-340); flagged_rounds [B] (optional) = number
+ *   of rounds for which the sample was still in `errors` (diagnostic).
+ * ------------------------------------------------------------------------------------------ */
+int og_sandwich_decode(const og_graph* g, int num_layers, const int* iters, const float* factors, const int* cn_types,
+                       const float* const* const* weights, float llr_const, const uint8_t* synd_x,
+                       const uint8_t* synd_z, int B, uint8_t* x_hat, uint8_t* z_hat, float* llr_final /*[B,3,n] or NULL*/,
+                       uint8_t* rounds /*[B] or NULL*/)
+{
+    const int n = g->n, mx = g->m[0], mz = g->m[1];
+    if (g->logit_rows[0].rows != mz || g->logit_rows[1].rows != mx) return -1; /* stage_one: pcm_x_perp=hz (:35-37) */
+#pragma omp parallel
+    {
+        og_scratch sc;
+        scratch_alloc(g, &sc);
+        float* llr = (float*)malloc(sizeof(float) * 3 * (size_t)n);
+        float* nl = (float*)malloc(sizeof(float) * 3 * (size_t)n);
+        float* xl = (float*)malloc(sizeof(float) * (size_t)(mz + 1));
+        float* zl = (float*)malloc(sizeof(float) * (size_t)(mx + 1));
+        float* work = (float*)malloc(sizeof(float) * gnn_work_floats(g));
+        uint8_t* xu = (uint8_t*)malloc((size_t)2 * n + mx + mz);
+        uint8_t* zu = xu + n;
+        uint8_t* st = zu + n;
+#pragma omp for schedule(dynamic, 2)
+        for (int b = 0; b < B; ++b) {
+            const uint8_t* sx = synd_x + (size_t)b * mx;
+            const uint8_t* sz = synd_z + (size_t)b * mz;
+            uint8_t* xh = x_hat + (size_t)b * n;
+            uint8_t* zh = z_hat + (size_t)b * n;
+            memset(sc.msg[0], 0, sizeof(float) * (size_t)g->E[0]);
+            memset(sc.msg[1], 0, sizeof(float) * (size_t)g->E[1]);
+            bp4_one(g, cn_types[0], iters[0], factors[0], NULL, llr_const, sx, sz, &sc, llr, xh, zh, xl, zl); /* (:321) */
+            int errors = 1, nr = 0; /* (:322) */
+            for (int i = 1; i < num_layers; ++i) {
+                /* flagged = syndrome of the MERGED estimate != true syndrome (:324-330) */
+                spmv2(g->cptr[1], g->cvn[1], mz, xh, st);      /* sx_hat = hz x_hat */
+                spmv2(g->cptr[0], g->cvn[0], mx, zh, st + mz); /* sz_hat = hx z_hat */
+                int neq = 0;
+                for (int c = 0; c < mz; ++c) neq |= (st[c] != sz[c]);       /* gt_x = hz noise_x = syndrome_z */
+                for (int c = 0; c < mx; ++c) neq |= (st[mz + c] != sx[c]);  /* gt_z = hx noise_z = syndrome_x */
+                errors = errors && neq;
+                nr += errors;
+                /* GNN on every sample with the latest marginals/logits (:333-335); note the swap:
+                 * feedbacks((h_vn, logit_hz_perp, logit_hx_perp, ...)): logit_hx := z_logit (rows of hx). */
+                gnn_one(g, weights[i - 1], llr, zl, xl, sx, sz, nl, work);
+                memset(sc.msg[0], 0, sizeof(float) * (size_t)g->E[0]);
+                memset(sc.msg[1], 0, sizeof(float) * (size_t)g->E[1]);
+                bp4_one(g, cn_types[i], iters[i], factors[i], nl, 0.0f, sx, sz, &sc, llr, xu, zu, xl, zl); /* (:336) */
+                if (errors) { /* (:339-340) */
+                    memcpy(xh, xu, (size_t)n);
+                    memcpy(zh, zu, (size_t)n);
+                }
+            }
+            if (llr_final) memcpy(llr_final + (size_t)b * 3 * n, llr, sizeof(float) * 3 * (size_t)n);
+            if (rounds) rounds[b] = (uint8_t)nr;
+        }
+        scratch_free(&sc);
+        free(llr);
+        free(nl);
+        free(xl);
+        free(zl);
+        free(work);
+        free(xu);
+    }
+    return 0;
+}
+
+/* elementwise wrappers so tests can probe the shared math from Python */
+void og_math_apply(int fn, const float* x, float* y, long nelem)
+{
+    for (long i = 0; i < nelem; ++i) {
+        float v = x[i];
+        switch (fn) {
+        case 0: y[i] = fg_exp(v); break;
+        case 1: y[i] = fg_log(v); break;
+        case 2: y[i] = fg_log1p(v); break;
+        case 3: y[i] = fg_softplus(v); break;
+        case 4: y[i] = fg_phi(v); break;
+        case 5: y[i] = fg_tanh(v); break;
+        case 6: y[i] = fg_atanh(v); break;
+        default: y[i] = 0.0f;
+        }
+    }
+}
+
+int og_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,205 @@
+"""ctypes binding of the CPU oracle (oracle/fgnn_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  The product package (feedback_gnn_amd) never imports this module.
+All arrays are NumPy, codeword-major (batch first), exactly the layouts of the C functions.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libfgnn_oracle.so")
+
+CN_TYPES = {"boxplus": 0, "boxplus-phi": 1, "minsum": 2}
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.og_graph_create.restype = C.c_void_p
+        _lib.og_graph_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p]
+        _lib.og_graph_set_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.og_graph_destroy.argtypes = [C.c_void_p]
+        _lib.og_bp4_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_float, C.c_void_p,
+                                       C.c_void_p, C.c_int] + [C.c_void_p] * 9
+        _lib.og_feedback_gnn.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_void_p]
+        _lib.og_pauli_noise.argtypes = [C.c_uint64, C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.og_syndrome.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.og_residual.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3
+        _lib.og_sandwich_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
+        _lib.og_math_apply.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+        _lib.og_num_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _coo(mat):
+    r, c = np.nonzero(np.asarray(mat))
+    return np.ascontiguousarray(r, dtype=np.int32), np.ascontiguousarray(c, dtype=np.int32)
+
+
+def num_threads():
+    return lib().og_num_threads()
+
+
+def math_apply(name, x):
+    fn = {"exp": 0, "log": 1, "log1p": 2, "softplus": 3, "phi": 4, "tanh": 5, "atanh": 6}[name]
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    lib().og_math_apply(fn, _p(x), _p(y), x.size)
+    return y
+
+
+class OracleGraph:
+    """Tanner graphs of a CSS code + the row sets the decoder needs.
+
+    ``stage_one=True`` uses pcm_x_perp = hz, pcm_z_perp = hx for the soft syndrome
+    (decoding_q.py:35-37); otherwise code.hx_perp / code.hz_perp.
+    """
+
+    def __init__(self, code, stage_one=True):
+        L = lib()
+        self.code = code
+        self.n = int(code.hx.shape[1])
+        self.m_x, self.m_z = int(code.hx.shape[0]), int(code.hz.shape[0])
+        rx, cx = _coo(code.hx)
+        rz, cz = _coo(code.hz)
+        self.E_x, self.E_z = len(rx), len(rz)
+        self.h = L.og_graph_create(self.n, self.m_x, self.m_z, self.E_x, _p(rx), _p(cx), self.E_z, _p(rz), _p(cz))
+        xp, zp = (code.hz, code.hx) if stage_one else (code.hx_perp, code.hz_perp)
+        self.rows_xp, self.rows_zp = int(xp.shape[0]), int(zp.shape[0])
+        for which, mat in ((0, xp), (1, zp), (2, code.hx_perp), (3, code.hz_perp)):
+            r, c = _coo(mat)
+            L.og_graph_set_rows(self.h, which, int(mat.shape[0]), len(r), _p(r), _p(c))
+        self.rows_hxp, self.rows_hzp = int(code.hx_perp.shape[0]), int(code.hz_perp.shape[0])
+
+    def __del__(self):
+        try:
+            lib().og_graph_destroy(self.h)
+        except Exception:
+            pass
+
+    # -- QLDPCBPDecoder.call ---------------------------------------------------------------
+    def bp4_decode(self, synd_x, synd_z, num_iter, cn_type="boxplus-phi", factor=1.0, llr_ch=None, llr_const=0.0,
+                   msg_init=None, return_msgs=False):
+        synd_x = np.ascontiguousarray(synd_x, dtype=np.uint8)
+        synd_z = np.ascontiguousarray(synd_z, dtype=np.uint8)
+        B = synd_x.shape[0]
+        assert synd_x.shape == (B, self.m_x) and synd_z.shape == (B, self.m_z)
+        if llr_ch is not None:
+            llr_ch = np.ascontiguousarray(llr_ch, dtype=np.float32)
+            assert llr_ch.shape == (B, 3, self.n)
+        mix = miz = None
+        if msg_init is not None:
+            mix = np.ascontiguousarray(msg_init[0], dtype=np.float32)
+            miz = np.ascontiguousarray(msg_init[1], dtype=np.float32)
+            assert mix.shape == (B, self.E_x) and miz.shape == (B, self.E_z)
+        llr = np.empty((B, 3, self.n), np.float32)
+        xh = np.empty((B, self.n), np.uint8)
+        zh = np.empty((B, self.n), np.uint8)
+        xl = np.empty((B, self.rows_xp), np.float32)
+        zl = np.empty((B, self.rows_zp), np.float32)
+        mox = np.empty((B, self.E_x), np.float32) if return_msgs else None
+        moz = np.empty((B, self.E_z), np.float32) if return_msgs else None
+        rc = lib().og_bp4_decode(self.h, CN_TYPES[cn_type], int(num_iter), float(factor), _p(llr_ch), float(llr_const),
+                                 _p(synd_x), _p(synd_z), B, _p(mix), _p(miz), _p(llr), _p(xh), _p(zh), _p(xl), _p(zl),
+                                 _p(mox), _p(moz))
+        assert rc == 0
+        out = dict(llr=llr, x_hat=xh, z_hat=zh, x_logit=xl, z_logit=zl)
+        if return_msgs:
+            out["msg_x"], out["msg_z"] = mox, moz
+        return out
+
+    # -- Feedback_GNN.call -------------------------------------------------------------------
+    def feedback_gnn(self, weights, llr, logit_hx, logit_hz, synd_x, synd_z):
+        w = [np.ascontiguousarray(a, dtype=np.float32) for a in weights]
+        wp = (C.c_void_p * 12)(*[a.ctypes.data for a in w])
+        llr = np.ascontiguousarray(llr, dtype=np.float32)
+        B = llr.shape[0]
+        logit_hx = np.ascontiguousarray(logit_hx, dtype=np.float32)
+        logit_hz = np.ascontiguousarray(logit_hz, dtype=np.float32)
+        synd_x = np.ascontiguousarray(synd_x, dtype=np.uint8)
+        synd_z = np.ascontiguousarray(synd_z, dtype=np.uint8)
+        assert llr.shape == (B, 3, self.n) and logit_hx.shape == (B, self.m_x) and logit_hz.shape == (B, self.m_z)
+        out = np.empty((B, 3, self.n), np.float32)
+        rc = lib().og_feedback_gnn(self.h, wp, _p(llr), _p(logit_hx), _p(logit_hz), _p(synd_x), _p(synd_z), B, _p(out))
+        assert rc == 0
+        return out
+
+    # -- channel / syndromes / residual -------------------------------------------------------
+    def pauli_noise(self, seed, p, first_sample, B):
+        ex = np.empty((B, self.n), np.uint8)
+        ez = np.empty((B, self.n), np.uint8)
+        lib().og_pauli_noise(int(seed), float(np.float32(p)), int(first_sample), B, self.n, _p(ex), _p(ez))
+        return ex, ez
+
+    def syndrome(self, ex, ez):
+        ex = np.ascontiguousarray(ex, dtype=np.uint8)
+        ez = np.ascontiguousarray(ez, dtype=np.uint8)
+        B = ex.shape[0]
+        sx = np.empty((B, self.m_x), np.uint8)
+        sz = np.empty((B, self.m_z), np.uint8)
+        lib().og_syndrome(self.h, _p(ex), _p(ez), B, _p(sx), _p(sz))
+        return sx, sz
+
+    def residual(self, ex, ez, xh, zh):
+        B = ex.shape[0]
+        s_hat = np.empty((B, self.m_z + self.m_x), np.uint8)
+        ls_hat = np.empty((B, self.rows_hxp + self.rows_hzp), np.uint8)
+        flags = np.empty((B,), np.uint8)
+        lib().og_residual(self.h, _p(np.ascontiguousarray(ex)), _p(np.ascontiguousarray(ez)),
+                          _p(np.ascontiguousarray(xh)), _p(np.ascontiguousarray(zh)), B, _p(s_hat), _p(ls_hat), _p(flags))
+        return s_hat, ls_hat, flags
+
+    # -- Sandwich_BP_GNN_Evaluation_Model.call (on given syndromes) -------------------------------
+    def sandwich_decode(self, synd_x, synd_z, iters, weights_list, llr_const, factors=None, cn_types=None,
+                        return_llr=False):
+        num_layers = len(iters)
+        assert len(weights_list) == num_layers - 1
+        factors = [1.0] * num_layers if factors is None else list(factors)
+        cn_types = ["boxplus-phi"] * num_layers if cn_types is None else list(cn_types)
+        it = np.asarray(iters, dtype=np.int32)
+        fa = np.asarray(factors, dtype=np.float32)
+        ct = np.asarray([CN_TYPES[c] for c in cn_types], dtype=np.int32)
+        keep = []
+        outer = (C.c_void_p * max(1, num_layers - 1))()
+        for i, wl in enumerate(weights_list):
+            w = [np.ascontiguousarray(a, dtype=np.float32) for a in wl]
+            inner = (C.c_void_p * 12)(*[a.ctypes.data for a in w])
+            keep.append((w, inner))
+            outer[i] = C.cast(inner, C.c_void_p).value
+        synd_x = np.ascontiguousarray(synd_x, dtype=np.uint8)
+        synd_z = np.ascontiguousarray(synd_z, dtype=np.uint8)
+        B = synd_x.shape[0]
+        xh = np.empty((B, self.n), np.uint8)
+        zh = np.empty((B, self.n), np.uint8)
+        llr = np.empty((B, 3, self.n), np.float32) if return_llr else None
+        rounds = np.empty((B,), np.uint8)
+        rc = lib().og_sandwich_decode(self.h, num_layers, _p(it), _p(fa), _p(ct), outer, float(llr_const), _p(synd_x),
+                                      _p(synd_z), B, _p(xh), _p(zh), _p(llr), _p(rounds))
+        assert rc == 0, rc
+        out = dict(x_hat=xh, z_hat=zh, rounds=rounds)
+        if return_llr:
+            out["llr"] = llr
+        return out
