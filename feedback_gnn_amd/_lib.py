@@ -1,0 +1,85 @@
+"""ctypes binding of libfgnn_hip.so (the C ABI declared in include/fgnn.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfgnn_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+CN_TYPES = {"boxplus": 0, "boxplus-phi": 1, "minsum": 2}
+ROWS_X_LOGIT, ROWS_Z_LOGIT, ROWS_HX_PERP, ROWS_HZ_PERP = 0, 1, 2, 3
+
+
+class FgnnError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise FgnnError("building libfgnn_hip.so failed")
+    return LIB_PATH
+
+
+_SIGNATURES = {
+    "fgnn_last_error": (C.c_char_p, []),
+    "fgnn_version": (C.c_int, []),
+    "fgnn_graph_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "fgnn_graph_destroy": (None, [C.c_void_p]),
+    "fgnn_graph_set_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "fgnn_graph_set_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "fgnn_graph_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fgnn_graph_edges": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "fgnn_bp4_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                  C.c_int] + [C.c_void_p] * 10),
+    "fgnn_weights_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "fgnn_weights_destroy": (None, [C.c_void_p]),
+    "fgnn_feedback_gnn": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_void_p]),
+    "fgnn_pauli_noise": (C.c_int, [C.c_uint64, C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fgnn_syndrome": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fgnn_flag_update": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p]),
+    "fgnn_merge": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fgnn_residual": (C.c_int, [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 4),
+    "fgnn_count_flags": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "fgnn_sandwich_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "fgnn_sandwich_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                       C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+}
+
+ABI_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """The loaded library (raises FgnnError if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FgnnError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU fallback for the decoder)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().fgnn_last_error().decode()
+        if rc == -1:
+            raise ValueError(msg)
+        raise FgnnError(f"libfgnn_hip error {rc}: {msg}")

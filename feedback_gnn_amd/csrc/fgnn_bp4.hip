@@ -1,0 +1,332 @@
+// fgnn_bp4.hip — quaternary belief propagation (BP4) over the two Tanner graphs of a CSS code,
+// LDS-resident: one workgroup keeps ALL messages of its codeword(s) in LDS for ALL iterations.
+//
+// Replaces QLDPCBPDecoder.call of /root/reference sionna/fec/ldpc/decoding_q.py:661-797, i.e. per
+// iteration _vn_update (:227-275), the CN-order gather (:752-753), _cn_update_{phi,minsum,tanh}
+// (:376-431 / :539-644 / :313-363), the normalisation (:759-760) and the gather back (:766-767);
+// then the marginals (:777), cal_logit (:455-471) and the hard decision (:783-790).
+//
+// The reference streams every [E,bs] message tensor through HBM ~10 times per half-iteration.
+// Here a codeword's state (E floats of messages + 3n channel LLRs, 32 KB for [[882,24]]) never
+// leaves the CU: HBM sees the syndromes once and the results once.  The kernel is therefore bound
+// by VALU issue (about 10^3 fma-class ops per qubit-iteration for the exact exp/log of
+// fgnn_math.h), not by HBM; DESIGN.md §4 gives the accounting next to the streaming-model figure.
+//
+// Message layout in LDS: slot e in [0,E_x) = hx edges, [E_x,E) = hz edges, both sorted by
+// (qubit, check).  The VN phase reads/writes a contiguous run per qubit; the CN phase gathers its
+// slots through g.cslot.  Updates are in place; two workgroup barriers per iteration.
+//
+// Summation order is the canonical one of the oracle (ascending neighbour index) and every
+// float op is the one the oracle executes, so results are bit-identical to oracle/fgnn_oracle.c.
+#include "fgnn_internal.h"
+#include "fgnn_math.h"
+
+namespace {
+
+struct BpArgs {
+    int B, num_iter, tpc, cpb, lds_per_cw, lch_off;  // per-codeword LDS floats; offset of the channel LLRs
+    float factor, llr_const;
+    const float* llr_ch;      // [B,3,n] or null
+    const uint8_t* synd_x;    // [B,m_x]
+    const uint8_t* synd_z;    // [B,m_z]
+    const float* msg_init_x;  // [B,E_x] or null
+    const float* msg_init_z;
+    float* llr_out;           // [B,3,n]
+    uint8_t* x_hat;
+    uint8_t* z_hat;
+    float* x_logit;           // [B,rows0] or null
+    float* z_logit;           // [B,rows1] or null
+    float* msg_out_x;
+    float* msg_out_z;
+    const int* index;         // optional: workgroup slot -> sample (compacted rounds of the sandwich driver)
+};
+
+__device__ __forceinline__ unsigned sign_bit(float x) { return fg_f2u(x) >> 31; }
+__device__ __forceinline__ float with_sign(float mag, unsigned neg) { return fg_u2f(fg_f2u(mag) ^ (neg << 31)); }
+
+// ---------------------------------------------------------------------------------------------
+// Check-node rules on runtime-degree rows.  `msg` = this codeword's LDS message array, `slot` =
+// the check's slot list.  Pass 1 parks |.|-type intermediates in the slots themselves (sign kept in
+// the sign bit), pass 2 writes the c->v messages.  decoding_q.py line numbers as in the oracle.
+// ---------------------------------------------------------------------------------------------
+template <int CN_TYPE>
+__device__ __forceinline__ void cn_update(float* msg, const int* __restrict__ slot, int deg, unsigned synd, float factor)
+{
+    if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI) {  // _cn_update_phi (:376-431)
+        unsigned neg = synd;
+        float T = 0.0f;
+        for (int j = 0; j < deg; ++j) {
+            int s = slot[j];
+            float v = msg[s];
+            unsigned ng = v < 0.0f;
+            neg ^= ng;
+            float a = fg_phi(FG_ABS(v));
+            T = T + a;
+            msg[s] = with_sign(a, ng);
+        }
+        for (int j = 0; j < deg; ++j) {
+            int s = slot[j];
+            float w = msg[s];
+            float out = fg_phi(T - FG_ABS(w));
+            msg[s] = with_sign(out, neg ^ sign_bit(w)) * factor;
+        }
+    } else if constexpr (CN_TYPE == FGNN_CN_MINSUM) {  // _cn_update_minsum (:539-644)
+        const float LARGE = 10000.0f;
+        unsigned neg = synd;
+        float minv = 0.0f;
+        for (int j = 0; j < deg; ++j) {
+            int s = slot[j];
+            float v = FG_MIN(FG_MAX(msg[s], -20.0f), 20.0f);
+            unsigned ng = v < 0.0f;
+            neg ^= ng;
+            float a = FG_ABS(v);
+            minv = (j == 0) ? a : FG_MIN(minv, a);
+            msg[s] = with_sign(a, ng);
+        }
+        float min2 = 0.0f, nsum = 0.0f;
+        for (int j = 0; j < deg; ++j) {
+            float d = FG_ABS(msg[slot[j]]) - minv;
+            d = (d == 0.0f) ? LARGE : d;
+            min2 = (j == 0) ? d : FG_MIN(min2, d);
+            nsum = nsum + d;
+        }
+        min2 = min2 + minv;
+        nsum = nsum - (2.0f * LARGE - 1.0f);
+        float sg = (nsum > 0.0f) ? 1.0f : ((nsum < 0.0f) ? -1.0f : 0.0f);
+        float dm = 0.5f * (1.0f - sg);
+        float min_e = (1.0f - dm) * minv + dm * min2;
+        for (int j = 0; j < deg; ++j) {
+            int s = slot[j];
+            float w = msg[s];
+            float d = FG_ABS(w) - minv;
+            float out = (d == 0.0f) ? min_e : minv;
+            msg[s] = with_sign(out, neg ^ sign_bit(w)) * factor;
+        }
+    } else {  // _cn_update_tanh (:313-363)
+        float P = 1.0f;
+        for (int j = 0; j < deg; ++j) {
+            int s = slot[j];
+            float t = fg_tanh(msg[s] / 2.0f);
+            t = (t == 0.0f) ? 1e-12f : t;
+            P = (j == 0) ? t : P * t;
+            msg[s] = t;
+        }
+        P = P * (synd ? -1.0f : 1.0f);
+        const float clipv = 0.99999988f;
+        for (int j = 0; j < deg; ++j) {
+            int s = slot[j];
+            float q = (1.0f / msg[s]) * P;
+            q = (FG_ABS(q) < 1e-7f) ? 0.0f : q;
+            q = FG_MIN(FG_MAX(q, -clipv), clipv);
+            msg[s] = (2.0f * fg_atanh(q)) * factor;
+        }
+    }
+}
+
+// soft syndrome of one row, _cn_update_phi_loss (:433-453)
+__device__ __forceinline__ float logit_row(const float* llr, const int* __restrict__ col, int deg)
+{
+    unsigned neg = 0;
+    float T = 0.0f;
+    for (int j = 0; j < deg; ++j) {
+        float v = llr[col[j]];
+        neg ^= (v < 0.0f);
+        T = T + fg_phi(FG_ABS(v));
+    }
+    return with_sign(fg_phi(T), neg);
+}
+
+template <int CN_TYPE>
+__global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
+{
+    extern __shared__ float lds[];
+    const int cwl = threadIdx.x / a.tpc;
+    const int lane = threadIdx.x - cwl * a.tpc;
+    const int slot_b = blockIdx.x * a.cpb + cwl;
+    const bool active = slot_b < a.B;  // padding codewords of the last block only keep the barriers company
+    const int b = (active && a.index) ? a.index[slot_b] : slot_b;
+    float* msg = lds + (size_t)cwl * a.lds_per_cw;
+    float* Lch = msg + a.lch_off;  // [3n], only when llr_ch != null
+    const int n = g.n;
+
+    if (active) {
+        for (int e = lane; e < g.E_x; e += a.tpc) msg[e] = a.msg_init_x ? a.msg_init_x[(size_t)b * g.E_x + e] : 0.0f;
+        for (int e = lane; e < g.E_z; e += a.tpc)
+            msg[g.E_x + e] = a.msg_init_z ? a.msg_init_z[(size_t)b * g.E_z + e] : 0.0f;
+        if (a.llr_ch)
+            for (int i = lane; i < 3 * n; i += a.tpc) Lch[i] = a.llr_ch[(size_t)b * 3 * n + i];
+    }
+    __syncthreads();
+
+    const uint8_t* sx = a.synd_x + (size_t)b * g.m_x;
+    const uint8_t* sz = a.synd_z + (size_t)b * g.m_z;
+
+    for (int it = 0; it < a.num_iter; ++it) {
+        // ---- variable nodes: _vn_update (:227-275) ----
+        if (active)
+            for (int v = lane; v < n; v += a.tpc) {
+                const int x0 = g.vptr_x[v], x1 = g.vptr_x[v + 1], z0 = g.vptr_z[v], z1 = g.vptr_z[v + 1];
+                float Sz = 0.0f, Sx = 0.0f;
+                for (int e = z0; e < z1; ++e) Sz = Sz + msg[e];
+                for (int e = x0; e < x1; ++e) Sx = Sx + msg[e];
+                const float lx = a.llr_ch ? Lch[v] : a.llr_const;
+                const float ly = a.llr_ch ? Lch[n + v] : a.llr_const;
+                const float lz = a.llr_ch ? Lch[2 * n + v] : a.llr_const;
+                const float Y = (Sz + Sx) + ly;
+                const float X = Sz + lx;
+                const float Z = Sx + lz;
+                const float numx = fg_softplus(-X);
+                const float numz = fg_softplus(-Z);
+                for (int e = x0; e < x1; ++e) {
+                    float m = msg[e];
+                    float Ze = Z - m, Ye = Y - m;
+                    msg[e] = numx - fg_lse2(-Ze, -Ye);
+                }
+                for (int e = z0; e < z1; ++e) {
+                    float m = msg[e];
+                    float Xe = X - m, Ye = Y - m;
+                    msg[e] = numz - fg_lse2(-Xe, -Ye);
+                }
+            }
+        __syncthreads();
+        // ---- check nodes of both graphs (:752-767) ----
+        if (active)
+            for (int c = lane; c < g.m; c += a.tpc) {
+                const int c0 = g.cptr[c], deg = g.cptr[c + 1] - c0;
+                const unsigned synd = (c < g.m_x ? sx[c] : sz[c - g.m_x]) & 1u;
+                cn_update<CN_TYPE>(msg, g.cslot + c0, deg, synd, a.factor);
+            }
+        __syncthreads();
+    }
+
+    // ---- marginals (:777), hard decision (:783-790), binary LLRs of cal_logit (:455-464) ----
+    if (active) {
+        if (a.msg_out_x)
+            for (int e = lane; e < g.E_x; e += a.tpc) a.msg_out_x[(size_t)b * g.E_x + e] = msg[e];
+        if (a.msg_out_z)
+            for (int e = lane; e < g.E_z; e += a.tpc) a.msg_out_z[(size_t)b * g.E_z + e] = msg[g.E_x + e];
+    }
+    // The binary LLRs go to LDS where the messages were; totals are computed first by every thread,
+    // parked in global memory (llr_out), and only then may the message area be overwritten.
+    if (active)
+        for (int v = lane; v < n; v += a.tpc) {
+            const int x0 = g.vptr_x[v], x1 = g.vptr_x[v + 1], z0 = g.vptr_z[v], z1 = g.vptr_z[v + 1];
+            float Sz = 0.0f, Sx = 0.0f;
+            for (int e = z0; e < z1; ++e) Sz = Sz + msg[e];
+            for (int e = x0; e < x1; ++e) Sx = Sx + msg[e];
+            const float lx = a.llr_ch ? Lch[v] : a.llr_const;
+            const float ly = a.llr_ch ? Lch[n + v] : a.llr_const;
+            const float lz = a.llr_ch ? Lch[2 * n + v] : a.llr_const;
+            const float Y = (Sz + Sx) + ly;
+            const float X = Sz + lx;
+            const float Z = Sx + lz;
+            float* o = a.llr_out + (size_t)b * 3 * n;
+            o[v] = X;
+            o[n + v] = Y;
+            o[2 * n + v] = Z;
+            int d = 0;
+            float best = 0.0f;
+            if (X < best) { best = X; d = 1; }
+            if (Z < best) { best = Z; d = 2; }
+            if (Y < best) { best = Y; d = 3; }
+            a.x_hat[(size_t)b * n + v] = (uint8_t)(d & 1);
+            a.z_hat[(size_t)b * n + v] = (uint8_t)(d >> 1);
+        }
+    if (!a.x_logit && !a.z_logit) return;
+    __syncthreads();  // every thread is done reading messages
+    float* llx = msg;      // [n] llr_x of cal_logit
+    float* llz = msg + n;  // [n] llr_z
+    if (active)
+        for (int v = lane; v < n; v += a.tpc) {
+            const float* o = a.llr_out + (size_t)b * 3 * n;
+            const float X = o[v], Y = o[n + v], Z = o[2 * n + v];  // own writes: visible to this thread
+            llz[v] = fg_softplus(-X) - fg_lse2(-Z, -Y);
+            llx[v] = fg_softplus(-Z) - fg_lse2(-X, -Y);
+        }
+    __syncthreads();
+    if (active) {
+        if (a.x_logit)
+            for (int r = lane; r < g.rows[0]; r += a.tpc) {
+                const int p0 = g.rptr[0][r];
+                a.x_logit[(size_t)b * g.rows[0] + r] = logit_row(llx, g.rcol[0] + p0, g.rptr[0][r + 1] - p0);
+            }
+        if (a.z_logit)
+            for (int r = lane; r < g.rows[1]; r += a.tpc) {
+                const int p0 = g.rptr[1][r];
+                a.z_logit[(size_t)b * g.rows[1] + r] = logit_row(llz, g.rcol[1] + p0, g.rptr[1][r + 1] - p0);
+            }
+    }
+}
+
+template <int CN_TYPE>
+int launch_bp4(const fgnn_graph* g, const BpArgs& a, const LaunchGeom& L, size_t lds_bytes, hipStream_t st)
+{
+    auto kern = bp4_kernel<CN_TYPE>;
+    if (lds_bytes > 48 * 1024)
+        FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(L.blocks), dim3(L.threads), lds_bytes, st, g->d, a);
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}
+
+}  // namespace
+
+int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float normalization_factor, const float* llr_ch,
+                         float llr_const, const uint8_t* synd_x, const uint8_t* synd_z, int B, const float* msg_init_x,
+                         const float* msg_init_z, float* llr_out, uint8_t* x_hat, uint8_t* z_hat, float* x_logit,
+                         float* z_logit, float* msg_out_x, float* msg_out_z, const int* index, void* stream)
+{
+    if (!g) return fgnn_fail(FGNN_ERR_ARG, "graph is NULL");
+    if (B < 0 || num_iter < 0) return fgnn_fail(FGNN_ERR_ARG, "B and num_iter must be >= 0");
+    if (cn_type < 0 || cn_type > 2) return fgnn_fail(FGNN_ERR_ARG, "Unknown node type.");  // decoding_q.py:107
+    if (!synd_x || !synd_z || !llr_out || !x_hat || !z_hat) return fgnn_fail(FGNN_ERR_ARG, "required buffer is NULL");
+    if ((x_logit && !g->d.rptr[0]) || (z_logit && !g->d.rptr[1]))
+        return fgnn_fail(FGNN_ERR_STATE, "logit row sets not installed (fgnn_graph_set_rows)");
+    if (B == 0) return FGNN_OK;
+    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    LaunchGeom L = fgnn_geom(g, B);
+    BpArgs a;
+    a.B = B;
+    a.num_iter = num_iter;
+    a.tpc = L.tpc;
+    a.cpb = L.cpb;
+    a.factor = normalization_factor;
+    a.llr_const = llr_const;
+    a.llr_ch = llr_ch;
+    a.synd_x = synd_x;
+    a.synd_z = synd_z;
+    a.msg_init_x = msg_init_x;
+    a.msg_init_z = msg_init_z;
+    a.llr_out = llr_out;
+    a.x_hat = x_hat;
+    a.z_hat = z_hat;
+    a.x_logit = x_logit;
+    a.z_logit = z_logit;
+    a.msg_out_x = msg_out_x;
+    a.msg_out_z = msg_out_z;
+    a.index = index;
+    // floats per codeword: messages (>= 2n so the epilogue's binary LLRs fit) + channel LLRs
+    a.lch_off = g->d.E > 2 * g->d.n ? g->d.E : 2 * g->d.n;
+    int per_cw = a.lch_off + (llr_ch ? 3 * g->d.n : 0);
+    per_cw = (per_cw + 3) & ~3;
+    a.lds_per_cw = per_cw;
+    size_t lds_bytes = (size_t)per_cw * sizeof(float) * (size_t)L.cpb;
+    if (lds_bytes > 160 * 1024) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident kernel");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (cn_type) {
+    case FGNN_CN_BOXPLUS_PHI: return launch_bp4<FGNN_CN_BOXPLUS_PHI>(g, a, L, lds_bytes, st);
+    case FGNN_CN_MINSUM: return launch_bp4<FGNN_CN_MINSUM>(g, a, L, lds_bytes, st);
+    default: return launch_bp4<FGNN_CN_BOXPLUS>(g, a, L, lds_bytes, st);
+    }
+}
+
+extern "C" int fgnn_bp4_decode(const fgnn_graph* g, int cn_type, int num_iter, float normalization_factor,
+                               const float* llr_ch, float llr_const, const uint8_t* synd_x, const uint8_t* synd_z, int B,
+                               const float* msg_init_x, const float* msg_init_z, float* llr_out, uint8_t* x_hat,
+                               uint8_t* z_hat, float* x_logit, float* z_logit, float* msg_out_x, float* msg_out_z,
+                               void* stream)
+{
+    return fgnn_bp4_decode_impl(g, cn_type, num_iter, normalization_factor, llr_ch, llr_const, synd_x, synd_z, B, msg_init_x,
+                                msg_init_z, llr_out, x_hat, z_hat, x_logit, z_logit, msg_out_x, msg_out_z, nullptr, stream);
+}

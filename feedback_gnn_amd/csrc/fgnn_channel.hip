@@ -1,0 +1,259 @@
+// fgnn_channel.hip — the integer/byte stages around the decoder: depolarizing noise, syndromes,
+// the per-round flag/merge logic and the residual check of
+// Sandwich_BP_GNN_Evaluation_Model.call (/root/reference sionna/fec/ldpc/feedback_gnn.py:293-361),
+// plus the block-error counting of sim_ber (sionna/utils/misc.py:647-669).
+//
+// The reference does all GF(2) products as dense int64 tf.matmul followed by `& 1`
+// (feedback_gnn.py:308-309, 324-325, 349-353).  Here they are XORs over CSR rows of uint8 vectors
+// held in LDS; every kernel is one workgroup per codeword-group with coalesced byte I/O.
+#include "fgnn_internal.h"
+#include "fgnn_math.h"
+#include "fgnn_rng.h"
+
+namespace {
+
+// Pauli.call, sionna/channel/pauli.py:98-108.  One thread = 4 qubits of one sample (one Philox block).
+__global__ void __launch_bounds__(256) pauli_kernel(uint64_t seed, float p, uint64_t first, int B, int n, int nblk,
+                                                    uint8_t* __restrict__ ex, uint8_t* __restrict__ ez)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)B * nblk) return;
+    const int b = (int)(t / nblk), blk = (int)(t - (long long)b * nblk);
+    const fg_pauli_thr thr = fg_pauli_thresholds(p);
+    float u[4];
+    fg_uniform4(seed, first + (uint64_t)b, (uint32_t)blk, u);
+    const int q0 = blk * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (q0 + k < n) {
+            ex[(size_t)b * n + q0 + k] = fg_pauli_x(u[k], thr);
+            ez[(size_t)b * n + q0 + k] = fg_pauli_z(u[k], thr);
+        }
+}
+
+__device__ __forceinline__ unsigned row_parity(const uint8_t* x, const int* __restrict__ col, int p0, int p1)
+{
+    unsigned a = 0;
+    for (int j = p0; j < p1; ++j) a ^= x[col[j]];
+    return a & 1u;
+}
+
+// syndrome_x = hx noise_z ; syndrome_z = hz noise_x  (feedback_gnn.py:305-309)
+__global__ void __launch_bounds__(1024) syndrome_kernel(GraphDev g, int B, int tpc, int cpb, const uint8_t* __restrict__ ex,
+                                                        const uint8_t* __restrict__ ez, uint8_t* __restrict__ sx,
+                                                        uint8_t* __restrict__ sz)
+{
+    extern __shared__ uint8_t sm[];
+    const int cwl = threadIdx.x / tpc, lane = threadIdx.x - cwl * tpc, b = blockIdx.x * cpb + cwl;
+    const bool active = b < B;
+    const int n = g.n;
+    uint8_t* lx = sm + (size_t)cwl * 2 * n;
+    uint8_t* lz = lx + n;
+    if (active)
+        for (int v = lane; v < n; v += tpc) {
+            lx[v] = ex[(size_t)b * n + v];
+            lz[v] = ez[(size_t)b * n + v];
+        }
+    __syncthreads();
+    if (!active) return;
+    for (int c = lane; c < g.m; c += tpc) {
+        const int p0 = g.cptr[c], p1 = g.cptr[c + 1];
+        if (c < g.m_x) sx[(size_t)b * g.m_x + c] = (uint8_t)row_parity(lz, g.cvn, p0, p1);
+        else sz[(size_t)b * g.m_z + (c - g.m_x)] = (uint8_t)row_parity(lx, g.cvn, p0, p1);
+    }
+}
+
+// errors &= any([hz x_hat ; hx z_hat] != [synd_z ; synd_x])   (feedback_gnn.py:324-330)
+__global__ void __launch_bounds__(1024) flag_kernel(GraphDev g, int B, int tpc, int cpb, const uint8_t* __restrict__ xh,
+                                                    const uint8_t* __restrict__ zh, const uint8_t* __restrict__ sx,
+                                                    const uint8_t* __restrict__ sz, uint8_t* __restrict__ errors)
+{
+    extern __shared__ uint8_t sm[];
+    const int cwl = threadIdx.x / tpc, lane = threadIdx.x - cwl * tpc, b = blockIdx.x * cpb + cwl;
+    const bool active = b < B;
+    const int n = g.n;
+    unsigned* neq = reinterpret_cast<unsigned*>(sm);  // [cpb]
+    uint8_t* lx = sm + ((cpb * sizeof(unsigned) + 15) & ~size_t(15)) + (size_t)cwl * 2 * n;
+    uint8_t* lz = lx + n;
+    if (lane == 0) neq[cwl] = 0;
+    if (active)
+        for (int v = lane; v < n; v += tpc) {
+            lx[v] = xh[(size_t)b * n + v];
+            lz[v] = zh[(size_t)b * n + v];
+        }
+    __syncthreads();
+    unsigned mine = 0;
+    if (active)
+        for (int c = lane; c < g.m; c += tpc) {
+            const int p0 = g.cptr[c], p1 = g.cptr[c + 1];
+            if (c < g.m_x) mine |= row_parity(lz, g.cvn, p0, p1) ^ (sx[(size_t)b * g.m_x + c] & 1u);
+            else mine |= row_parity(lx, g.cvn, p0, p1) ^ (sz[(size_t)b * g.m_z + (c - g.m_x)] & 1u);
+        }
+    if (mine) atomicOr(&neq[cwl], 1u);
+    __syncthreads();
+    if (active && lane == 0) errors[b] = (uint8_t)((errors[b] != 0) && (neq[cwl] != 0));
+}
+
+// masked overwrite of the estimates (feedback_gnn.py:339-340)
+__global__ void __launch_bounds__(256) merge_kernel(const uint8_t* __restrict__ errors, const uint8_t* __restrict__ xu,
+                                                    const uint8_t* __restrict__ zu, long long total, int n,
+                                                    uint8_t* __restrict__ xh, uint8_t* __restrict__ zh)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    if (errors[i / n]) {
+        xh[i] = xu[i];
+        zh[i] = zu[i];
+    }
+}
+
+// residual check (feedback_gnn.py:343-361) + row-wise any() (metrics.py:221-223)
+__global__ void __launch_bounds__(1024) residual_kernel(GraphDev g, int B, int tpc, int cpb, const uint8_t* __restrict__ ex,
+                                                        const uint8_t* __restrict__ ez, const uint8_t* __restrict__ xh,
+                                                        const uint8_t* __restrict__ zh, uint8_t* __restrict__ s_hat,
+                                                        uint8_t* __restrict__ ls_hat, uint8_t* __restrict__ flags)
+{
+    extern __shared__ uint8_t sm[];
+    const int cwl = threadIdx.x / tpc, lane = threadIdx.x - cwl * tpc, b = blockIdx.x * cpb + cwl;
+    const bool active = b < B;
+    const int n = g.n;
+    unsigned* fl = reinterpret_cast<unsigned*>(sm);  // [cpb]
+    uint8_t* xd = sm + ((cpb * sizeof(unsigned) + 15) & ~size_t(15)) + (size_t)cwl * 2 * n;
+    uint8_t* zd = xd + n;
+    if (lane == 0) fl[cwl] = 0;
+    if (active)
+        for (int v = lane; v < n; v += tpc) {
+            xd[v] = ex[(size_t)b * n + v] ^ xh[(size_t)b * n + v];  // (:346)
+            zd[v] = ez[(size_t)b * n + v] ^ zh[(size_t)b * n + v];  // (:347)
+        }
+    __syncthreads();
+    unsigned mine = 0;
+    if (active) {
+        const int ms = g.m_z + g.m_x;
+        // s_hat = [hz xd ; hx zd]  (:349-350,:355): combined check c: hx rows first, so remap
+        for (int c = lane; c < g.m; c += tpc) {
+            const int p0 = g.cptr[c], p1 = g.cptr[c + 1];
+            unsigned bit;
+            int pos;
+            if (c < g.m_x) { bit = row_parity(zd, g.cvn, p0, p1); pos = g.m_z + c; }
+            else { bit = row_parity(xd, g.cvn, p0, p1); pos = c - g.m_x; }
+            if (s_hat) s_hat[(size_t)b * ms + pos] = (uint8_t)bit;
+            mine |= bit;
+        }
+        // ls_hat = [hx_perp xd ; hz_perp zd]  (:352-353,:356)
+        const int r0 = g.rows[FGNN_ROWS_HX_PERP], r1 = g.rows[FGNN_ROWS_HZ_PERP];
+        for (int r = lane; r < r0 + r1; r += tpc) {
+            unsigned bit;
+            if (r < r0) bit = row_parity(xd, g.rcol[FGNN_ROWS_HX_PERP], g.rptr[FGNN_ROWS_HX_PERP][r], g.rptr[FGNN_ROWS_HX_PERP][r + 1]);
+            else bit = row_parity(zd, g.rcol[FGNN_ROWS_HZ_PERP], g.rptr[FGNN_ROWS_HZ_PERP][r - r0], g.rptr[FGNN_ROWS_HZ_PERP][r - r0 + 1]);
+            if (ls_hat) ls_hat[(size_t)b * (r0 + r1) + r] = (uint8_t)bit;
+            mine |= bit << 1;
+        }
+    }
+    if (mine) atomicOr(&fl[cwl], mine);
+    __syncthreads();
+    if (active && lane == 0 && flags) flags[b] = (uint8_t)fl[cwl];
+}
+
+__global__ void __launch_bounds__(256) count_kernel(const uint8_t* __restrict__ flags, int B, unsigned long long* counts)
+{
+    __shared__ unsigned sh[2];
+    if (threadIdx.x < 2) sh[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned f = 0, l = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+        f += flags[i] & 1u;
+        l += (flags[i] >> 1) & 1u;
+    }
+    if (f) atomicAdd(&sh[0], f);
+    if (l) atomicAdd(&sh[1], l);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (sh[0]) atomicAdd(&counts[0], (unsigned long long)sh[0]);
+        if (sh[1]) atomicAdd(&counts[1], (unsigned long long)sh[1]);
+        if (blockIdx.x == 0) atomicAdd(&counts[2], (unsigned long long)B);
+    }
+}
+
+}  // namespace
+
+extern "C" int fgnn_pauli_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, uint8_t* noise_x,
+                                uint8_t* noise_z, void* stream)
+{
+    if (B < 0 || n <= 0 || !noise_x || !noise_z) return fgnn_fail(FGNN_ERR_ARG, "bad noise arguments");
+    if (B == 0) return FGNN_OK;
+    const int nblk = (n + 3) / 4;
+    const long long total = (long long)B * nblk;
+    hipLaunchKernelGGL(pauli_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), seed,
+                       p, first_sample, B, n, nblk, noise_x, noise_z);
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_syndrome(const fgnn_graph* g, const uint8_t* noise_x, const uint8_t* noise_z, int B, uint8_t* synd_x,
+                             uint8_t* synd_z, void* stream)
+{
+    if (!g || !noise_x || !noise_z || !synd_x || !synd_z || B < 0) return fgnn_fail(FGNN_ERR_ARG, "bad syndrome arguments");
+    if (B == 0) return FGNN_OK;
+    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    LaunchGeom L = fgnn_geom(g, B);
+    size_t lds = (size_t)L.cpb * 2 * g->d.n;
+    hipLaunchKernelGGL(syndrome_kernel, dim3(L.blocks), dim3(L.threads), lds, static_cast<hipStream_t>(stream), g->d, B, L.tpc,
+                       L.cpb, noise_x, noise_z, synd_x, synd_z);
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_flag_update(const fgnn_graph* g, const uint8_t* x_hat, const uint8_t* z_hat, const uint8_t* synd_x,
+                                const uint8_t* synd_z, int B, uint8_t* errors, void* stream)
+{
+    if (!g || !x_hat || !z_hat || !synd_x || !synd_z || !errors || B < 0) return fgnn_fail(FGNN_ERR_ARG, "bad flag arguments");
+    if (B == 0) return FGNN_OK;
+    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    LaunchGeom L = fgnn_geom(g, B);
+    size_t lds = ((L.cpb * sizeof(unsigned) + 15) & ~size_t(15)) + (size_t)L.cpb * 2 * g->d.n;
+    hipLaunchKernelGGL(flag_kernel, dim3(L.blocks), dim3(L.threads), lds, static_cast<hipStream_t>(stream), g->d, B, L.tpc, L.cpb,
+                       x_hat, z_hat, synd_x, synd_z, errors);
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_merge(const uint8_t* errors, const uint8_t* x_upd, const uint8_t* z_upd, int B, int n, uint8_t* x_hat,
+                          uint8_t* z_hat, void* stream)
+{
+    if (!errors || !x_upd || !z_upd || !x_hat || !z_hat || B < 0 || n <= 0) return fgnn_fail(FGNN_ERR_ARG, "bad merge arguments");
+    if (B == 0) return FGNN_OK;
+    const long long total = (long long)B * n;
+    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), errors,
+                       x_upd, z_upd, total, n, x_hat, z_hat);
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_residual(const fgnn_graph* g, const uint8_t* noise_x, const uint8_t* noise_z, const uint8_t* x_hat,
+                             const uint8_t* z_hat, int B, uint8_t* s_hat, uint8_t* ls_hat, uint8_t* flags, void* stream)
+{
+    if (!g || !noise_x || !noise_z || !x_hat || !z_hat || B < 0) return fgnn_fail(FGNN_ERR_ARG, "bad residual arguments");
+    if (!g->d.rptr[FGNN_ROWS_HX_PERP] || !g->d.rptr[FGNN_ROWS_HZ_PERP])
+        return fgnn_fail(FGNN_ERR_STATE, "hx_perp / hz_perp row sets not installed (fgnn_graph_set_rows)");
+    if (B == 0) return FGNN_OK;
+    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    LaunchGeom L = fgnn_geom(g, B);
+    size_t lds = ((L.cpb * sizeof(unsigned) + 15) & ~size_t(15)) + (size_t)L.cpb * 2 * g->d.n;
+    hipLaunchKernelGGL(residual_kernel, dim3(L.blocks), dim3(L.threads), lds, static_cast<hipStream_t>(stream), g->d, B, L.tpc,
+                       L.cpb, noise_x, noise_z, x_hat, z_hat, s_hat, ls_hat, flags);
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_count_flags(const uint8_t* flags, int B, uint64_t* counts, void* stream)
+{
+    if (!flags || !counts || B < 0) return fgnn_fail(FGNN_ERR_ARG, "bad count arguments");
+    if (B == 0) return FGNN_OK;
+    int blocks = (B + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(count_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), flags, B,
+                       reinterpret_cast<unsigned long long*>(counts));
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}

@@ -1,0 +1,254 @@
+// fgnn_graph.hip — builds the device-resident Tanner-graph tables of a CSS code.
+// Replaces the edge bookkeeping of QLDPCBPDecoder.__init__ (/root/reference
+// sionna/fec/ldpc/decoding_q.py:53-94: scipy.sparse.find + argsort + ragged row splits) and of
+// Feedback_GNN.create_edges (feedback_gnn.py:87-108) by one CSC + one CSR view per parity-check matrix.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "fgnn_internal.h"
+
+static thread_local std::string g_err;
+void fgnn_set_error(const std::string& s) { g_err = s; }
+int fgnn_fail(int code, const std::string& s)
+{
+    g_err = s;
+    return code;
+}
+extern "C" const char* fgnn_last_error(void) { return g_err.c_str(); }
+extern "C" int fgnn_version(void) { return 1; }
+
+namespace {
+
+template <typename T>
+int upload(fgnn_graph* g, const std::vector<T>& h, const T** dst)
+{
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    FGNN_HIP_CHECK(hipMalloc(&p, bytes));
+    g->allocs.push_back(p);
+    if (!h.empty()) FGNN_HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<const T*>(p);
+    return FGNN_OK;
+}
+
+// COO -> CSR with ascending columns inside each row
+void coo_to_csr(int rows, int nnz, const int32_t* r, const int32_t* c, std::vector<int>& ptr, std::vector<int>& col)
+{
+    std::vector<int> order(nnz);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return r[a] != r[b] ? r[a] < r[b] : c[a] < c[b]; });
+    ptr.assign(rows + 1, 0);
+    col.resize(nnz);
+    for (int i = 0; i < nnz; ++i) {
+        ptr[r[order[i]] + 1]++;
+        col[i] = c[order[i]];
+    }
+    for (int i = 0; i < rows; ++i) ptr[i + 1] += ptr[i];
+}
+
+int uniform_degree(const std::vector<int>& ptr)
+{
+    if (ptr.size() < 2) return 0;
+    int d = ptr[1] - ptr[0];
+    for (size_t i = 1; i + 1 < ptr.size(); ++i)
+        if (ptr[i + 1] - ptr[i] != d) return 0;
+    return d;
+}
+
+void default_launch(fgnn_graph* g)
+{
+    // One thread per node-slot; a codeword gets ceil(nodes / npt) threads with npt chosen so that a
+    // workgroup stays <= 512 threads where possible (several workgroups per CU hide each other's
+    // barriers).  Small codes pack several codewords into one workgroup.
+    const int nodes = std::max(g->d.n, g->d.m);
+    int npt = (nodes + 511) / 512;
+    int tpc = (nodes + npt - 1) / npt;
+    int cpb = 1;
+    if (tpc >= 64) {
+        tpc = (tpc + 63) / 64 * 64;
+    } else {
+        int p2 = 1;
+        while (p2 < tpc) p2 <<= 1;
+        tpc = p2;
+        cpb = 256 / tpc;
+    }
+    g->tpc = tpc;
+    g->cpb = cpb;
+}
+
+}  // namespace
+
+LaunchGeom fgnn_geom(const fgnn_graph* g, int B)
+{
+    LaunchGeom L;
+    L.tpc = g->tpc;
+    L.cpb = g->cpb;
+    L.threads = g->tpc * g->cpb;
+    L.blocks = (B + g->cpb - 1) / g->cpb;
+    return L;
+}
+
+extern "C" int fgnn_graph_create(int n, int m_x, int m_z, int nnz_x, const int32_t* chk_x, const int32_t* var_x,
+                                 int nnz_z, const int32_t* chk_z, const int32_t* var_z, int device, fgnn_graph** out)
+{
+    if (!out) return fgnn_fail(FGNN_ERR_ARG, "out is NULL");
+    if (n <= 0 || m_x <= 0 || m_z <= 0 || nnz_x <= 0 || nnz_z <= 0)
+        return fgnn_fail(FGNN_ERR_ARG, "n, m_x, m_z and the edge counts must be positive");
+    const int32_t* chk[2] = {chk_x, chk_z};
+    const int32_t* var[2] = {var_x, var_z};
+    const int nnz[2] = {nnz_x, nnz_z};
+    const int m[2] = {m_x, m_z};
+    for (int s = 0; s < 2; ++s)
+        for (int i = 0; i < nnz[s]; ++i)
+            if (chk[s][i] < 0 || chk[s][i] >= m[s] || var[s][i] < 0 || var[s][i] >= n)
+                return fgnn_fail(FGNN_ERR_ARG, "edge index out of range");
+    FGNN_HIP_CHECK(hipSetDevice(device));
+    fgnn_graph* g = new fgnn_graph();
+    std::memset(&g->d, 0, sizeof(g->d));
+    std::memset(g->row_alloc, 0, sizeof(g->row_alloc));
+    g->device = device;
+    g->user_launch = false;
+    GraphDev& d = g->d;
+    d.n = n;
+    d.m_x = m_x;
+    d.m_z = m_z;
+    d.m = m_x + m_z;
+    d.E_x = nnz_x;
+    d.E_z = nnz_z;
+    d.E = nnz_x + nnz_z;
+
+    std::vector<int> vptr[2], vchk_side[2];
+    for (int s = 0; s < 2; ++s) {
+        coo_to_csr(n, nnz[s], var[s], chk[s], vptr[s], vchk_side[s]);  // rows = qubits
+        for (int v = 0; v < n; ++v)
+            for (int e = vptr[s][v]; e + 1 < vptr[s][v + 1]; ++e)
+                if (vchk_side[s][e] == vchk_side[s][e + 1]) {
+                    delete g;
+                    return fgnn_fail(FGNN_ERR_ARG, "duplicate edge");
+                }
+        g->h_chk[s] = std::vector<int32_t>(vchk_side[s].begin(), vchk_side[s].end());
+        g->h_var[s].resize(nnz[s]);
+        for (int v = 0; v < n; ++v)
+            for (int e = vptr[s][v]; e < vptr[s][v + 1]; ++e) g->h_var[s][e] = v;
+    }
+    // combined VN-major check ids and slot offsets
+    std::vector<int> vptr_x = vptr[0], vptr_z = vptr[1], vchk(d.E);
+    for (auto& x : vptr_z) x += d.E_x;
+    std::copy(vchk_side[0].begin(), vchk_side[0].end(), vchk.begin());
+    std::copy(vchk_side[1].begin(), vchk_side[1].end(), vchk.begin() + d.E_x);
+    // combined CN-major view
+    std::vector<int> cptr(d.m + 1, 0), cslot(d.E), cvn(d.E);
+    {
+        std::vector<int> deg(d.m, 0);
+        for (int s = 0; s < 2; ++s)
+            for (int i = 0; i < nnz[s]; ++i) deg[(s ? m_x : 0) + chk[s][i]]++;
+        for (int c = 0; c < d.m; ++c) cptr[c + 1] = cptr[c] + deg[c];
+        std::vector<int> fill(d.m, 0);
+        // walking qubits in ascending order fills every check's list in ascending qubit order
+        for (int s = 0; s < 2; ++s)
+            for (int v = 0; v < n; ++v)
+                for (int e = vptr[s][v]; e < vptr[s][v + 1]; ++e) {
+                    int c = (s ? m_x : 0) + vchk_side[s][e];
+                    int pos = cptr[c] + fill[c]++;
+                    cslot[pos] = e + (s ? d.E_x : 0);
+                    cvn[pos] = v;
+                }
+    }
+    d.dvx = uniform_degree(vptr[0]);
+    d.dvz = uniform_degree(vptr[1]);
+    d.dc = uniform_degree(cptr);
+    int rc;
+    if ((rc = upload(g, vptr_x, &d.vptr_x)) || (rc = upload(g, vptr_z, &d.vptr_z)) || (rc = upload(g, vchk, &d.vchk)) ||
+        (rc = upload(g, cptr, &d.cptr)) || (rc = upload(g, cslot, &d.cslot)) || (rc = upload(g, cvn, &d.cvn))) {
+        fgnn_graph_destroy(g);
+        return rc;
+    }
+    default_launch(g);
+    *out = g;
+    return FGNN_OK;
+}
+
+extern "C" void fgnn_graph_destroy(fgnn_graph* g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    for (void* p : g->allocs) (void)hipFree(p);
+    for (auto& r : g->row_alloc)
+        for (void* p : r)
+            if (p) (void)hipFree(p);
+    delete g;
+}
+
+extern "C" int fgnn_graph_set_rows(fgnn_graph* g, int which, int rows, int nnz, const int32_t* row, const int32_t* col)
+{
+    if (!g || which < 0 || which > 3 || rows < 0 || nnz < 0) return fgnn_fail(FGNN_ERR_ARG, "bad row-set arguments");
+    for (int i = 0; i < nnz; ++i)
+        if (row[i] < 0 || row[i] >= rows || col[i] < 0 || col[i] >= g->d.n)
+            return fgnn_fail(FGNN_ERR_ARG, "row-set index out of range");
+    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    std::vector<int> ptr, c;
+    coo_to_csr(rows, nnz, row, col, ptr, c);
+    for (void*& p : g->row_alloc[which])
+        if (p) {
+            (void)hipFree(p);
+            p = nullptr;
+        }
+    void *dp = nullptr, *dc = nullptr;
+    FGNN_HIP_CHECK(hipMalloc(&dp, ptr.size() * sizeof(int)));
+    g->row_alloc[which][0] = dp;
+    FGNN_HIP_CHECK(hipMalloc(&dc, std::max<size_t>(c.size(), 1) * sizeof(int)));
+    g->row_alloc[which][1] = dc;
+    FGNN_HIP_CHECK(hipMemcpy(dp, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (!c.empty()) FGNN_HIP_CHECK(hipMemcpy(dc, c.data(), c.size() * sizeof(int), hipMemcpyHostToDevice));
+    g->d.rows[which] = rows;
+    g->d.rptr[which] = static_cast<const int*>(dp);
+    g->d.rcol[which] = static_cast<const int*>(dc);
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords_per_block)
+{
+    if (!g) return fgnn_fail(FGNN_ERR_ARG, "graph is NULL");
+    if (threads_per_codeword <= 0 && codewords_per_block <= 0) {
+        default_launch(g);
+        g->user_launch = false;
+        return FGNN_OK;
+    }
+    int tpc = threads_per_codeword > 0 ? threads_per_codeword : g->tpc;
+    int cpb = codewords_per_block > 0 ? codewords_per_block : 1;
+    if (tpc * cpb > 1024 || (tpc * cpb) % 64 != 0)
+        return fgnn_fail(FGNN_ERR_ARG, "threads_per_codeword*codewords_per_block must be a multiple of 64 and <= 1024");
+    g->tpc = tpc;
+    g->cpb = cpb;
+    g->user_launch = true;
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_graph_info(const fgnn_graph* g, int32_t info[16])
+{
+    if (!g || !info) return fgnn_fail(FGNN_ERR_ARG, "NULL argument");
+    std::memset(info, 0, 16 * sizeof(int32_t));
+    info[0] = g->d.n;
+    info[1] = g->d.m_x;
+    info[2] = g->d.m_z;
+    info[3] = g->d.E_x;
+    info[4] = g->d.E_z;
+    info[5] = g->tpc;
+    info[6] = g->cpb;
+    info[7] = (int)((size_t)g->cpb * (size_t)(g->d.E + 3 * g->d.n) * sizeof(float));
+    info[8] = (g->d.dvx > 0 && g->d.dvz > 0 && g->d.dc > 0) ? 1 : 0;
+    info[9] = g->device;
+    info[10] = g->d.dvx;
+    info[11] = g->d.dvz;
+    info[12] = g->d.dc;
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_graph_edges(const fgnn_graph* g, int side, int32_t* chk, int32_t* var)
+{
+    if (!g || side < 0 || side > 1 || !chk || !var) return fgnn_fail(FGNN_ERR_ARG, "bad arguments");
+    std::copy(g->h_chk[side].begin(), g->h_chk[side].end(), chk);
+    std::copy(g->h_var[side].begin(), g->h_var[side].end(), var);
+    return FGNN_OK;
+}

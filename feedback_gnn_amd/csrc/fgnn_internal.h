@@ -1,0 +1,80 @@
+// fgnn_internal.h — shared declarations of libfgnn_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/fgnn.h"
+
+// Device view of one CSS code.  Messages of one codeword live in ONE array of E = E_x + E_z floats:
+// slots [0,E_x) are the hx edges, [E_x,E) the hz edges, each block sorted by (qubit, check)
+// ("VN-major"), so a variable node owns a contiguous run per side and a check node gathers.
+struct GraphDev {
+    int n, m_x, m_z, m, E_x, E_z, E;
+    const int* vptr_x;  // [n+1] first hx slot of qubit v
+    const int* vptr_z;  // [n+1] first hz slot of qubit v (already offset by E_x)
+    const int* vchk;    // [E]   check id (0..m_x-1 / 0..m_z-1) of each VN-major slot
+    const int* cptr;    // [m+1] combined checks: hx rows 0..m_x-1 then hz rows; offsets into cslot/cvn
+    const int* cslot;   // [E]   message slot of the k-th edge of a check (ascending qubit)
+    const int* cvn;     // [E]   qubit of that edge
+    // CSR row sets (fgnn_graph_set_rows)
+    int rows[4];
+    const int* rptr[4];
+    const int* rcol[4];
+    // uniform degrees, 0 if irregular
+    int dvx, dvz, dc;
+};
+
+struct fgnn_graph {
+    GraphDev d;
+    int device;
+    int tpc, cpb;  // threads per codeword, codewords per block
+    bool user_launch;
+    std::vector<void*> allocs;
+    // host copies of the canonical edge lists (fgnn_graph_edges)
+    std::vector<int32_t> h_chk[2], h_var[2];
+    void* row_alloc[4][2];
+};
+
+// Device layout of one feedback GNN (transposed where that makes the scalar loads contiguous).
+struct WeightsDev {
+    const float* w1t[2];  // [40][4]  W1^T of vn_msg_mlp_{x,z}
+    const float* b1[2];   // [40]
+    const float* w2[2];   // [40][20]
+    const float* b2[2];   // [20]
+    const float* wet;     // [40][44] We^T (k padded 43 -> 44 with 0)
+    const float* be;      // [40]
+    const float* wout;    // [40][4]  (3 padded to 4)
+    const float* bout;    // [4]
+};
+
+struct fgnn_weights {
+    WeightsDev d;
+    int device;
+    void* blob;
+};
+
+void fgnn_set_error(const std::string& s);
+int fgnn_fail(int code, const std::string& s);
+#define FGNN_HIP_CHECK(expr)                                                                          \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return fgnn_fail(FGNN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+    } while (0)
+
+// launch geometry shared by the per-codeword kernels
+struct LaunchGeom {
+    int tpc, cpb, threads, blocks;
+};
+LaunchGeom fgnn_geom(const fgnn_graph* g, int B);
+
+// internal entry points with an optional slot->sample indirection (compacted sandwich rounds)
+int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float normalization_factor, const float* llr_ch,
+                         float llr_const, const uint8_t* synd_x, const uint8_t* synd_z, int B, const float* msg_init_x,
+                         const float* msg_init_z, float* llr_out, uint8_t* x_hat, uint8_t* z_hat, float* x_logit,
+                         float* z_logit, float* msg_out_x, float* msg_out_z, const int* index, void* stream);
+int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const float* llr, const float* logit_hx,
+                           const float* logit_hz, const uint8_t* synd_x, const uint8_t* synd_z, int B, float* out,
+                           const int* index, void* stream);

@@ -1,0 +1,146 @@
+// fgnn_sandwich.hip — device-side driver of the BP / GNN / BP ... sandwich.
+//
+// Replaces the body of Sandwich_BP_GNN_Evaluation_Model.call between the syndrome computation
+// and the residual check (/root/reference sionna/fec/ldpc/feedback_gnn.py:321-340):
+//     decoders[0]; errors = all-true
+//     for i in 1..num_layers-1:  errors &= flagged(x_hat, z_hat);  new_llr = G_{i-1}(...);
+//                                 decoders[i](new_llr);  merge where errors
+// Everything is enqueued on the caller's stream; intermediate tensors live in the caller's
+// workspace.  With compact != 0 each round runs only on the samples still in `errors` (the
+// reference cannot: XLA needs static shapes, so it decodes all samples and masks the merge,
+// :333-340) — x_hat/z_hat are identical either way because a sample that left `errors` is never
+// merged again.  Compaction costs one 4-byte device->host read per round.
+#include "fgnn_internal.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) fill_u8(uint8_t* p, uint8_t v, int count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = v;
+}
+
+__global__ void __launch_bounds__(256) rounds_add(const uint8_t* __restrict__ errors, uint8_t* __restrict__ rounds, int B)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) rounds[i] = (uint8_t)(rounds[i] + (errors[i] ? 1 : 0));
+}
+
+// index list of the samples with errors[b] != 0; ascending order inside each 256-sample block,
+// blocks appended in arrival order (the order only affects which workgroup decodes which sample)
+__global__ void __launch_bounds__(256) compact_kernel(const uint8_t* __restrict__ errors, int B, int* __restrict__ index,
+                                                      int* __restrict__ count)
+{
+    __shared__ int base;
+    __shared__ int wsum[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = (i < B) && errors[i];
+    const unsigned long long ball = __ballot(on);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) wsum[wave] = __popcll(ball);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        base = tot ? atomicAdd(count, tot) : 0;
+    }
+    __syncthreads();
+    if (on) {
+        int off = base + __popcll(ball & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        index[off] = i;
+    }
+}
+
+struct Workspace {
+    float *llr_a, *llr_b, *xlogit, *zlogit;
+    uint8_t *x_upd, *z_upd, *errors;
+    int *index, *count;
+};
+
+size_t carve(const fgnn_graph* g, int B, void* base, Workspace* ws)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~size_t(255);
+        return base ? static_cast<char*>(base) + o : nullptr;
+    };
+    const size_t n = g->d.n;
+    char* p;
+    p = take(sizeof(float) * 3 * n * B); if (ws) ws->llr_a = reinterpret_cast<float*>(p);
+    p = take(sizeof(float) * 3 * n * B); if (ws) ws->llr_b = reinterpret_cast<float*>(p);
+    p = take(sizeof(float) * (size_t)g->d.m_z * B); if (ws) ws->xlogit = reinterpret_cast<float*>(p);
+    p = take(sizeof(float) * (size_t)g->d.m_x * B); if (ws) ws->zlogit = reinterpret_cast<float*>(p);
+    p = take(n * B); if (ws) ws->x_upd = reinterpret_cast<uint8_t*>(p);
+    p = take(n * B); if (ws) ws->z_upd = reinterpret_cast<uint8_t*>(p);
+    p = take((size_t)B); if (ws) ws->errors = reinterpret_cast<uint8_t*>(p);
+    p = take(sizeof(int) * (size_t)B); if (ws) ws->index = reinterpret_cast<int*>(p);
+    p = take(sizeof(int) * 64); if (ws) ws->count = reinterpret_cast<int*>(p);
+    return off;
+}
+
+}  // namespace
+
+extern "C" size_t fgnn_sandwich_workspace_bytes(const fgnn_graph* g, int B)
+{
+    if (!g || B <= 0) return 0;
+    return carve(g, B, nullptr, nullptr);
+}
+
+extern "C" int fgnn_sandwich_decode(const fgnn_graph* g, int num_layers, const int32_t* iters, const float* factors,
+                                    const int32_t* cn_types, const fgnn_weights* const* weights, float llr_const,
+                                    const uint8_t* synd_x, const uint8_t* synd_z, int B, int compact, uint8_t* x_hat,
+                                    uint8_t* z_hat, float* llr_final, uint8_t* rounds, void* workspace, size_t ws_bytes,
+                                    void* stream)
+{
+    if (!g || num_layers < 1 || !iters || !factors || !cn_types) return fgnn_fail(FGNN_ERR_ARG, "bad sandwich configuration");
+    if (num_layers > 1 && !weights) return fgnn_fail(FGNN_ERR_ARG, "weights is NULL");
+    if (!synd_x || !synd_z || !x_hat || !z_hat || B < 0) return fgnn_fail(FGNN_ERR_ARG, "required buffer is NULL");
+    if (g->d.rows[FGNN_ROWS_X_LOGIT] != g->d.m_z || g->d.rows[FGNN_ROWS_Z_LOGIT] != g->d.m_x)
+        return fgnn_fail(FGNN_ERR_STATE, "sandwich needs stage_one logit rows (pcm_x_perp=hz, pcm_z_perp=hx)");
+    if (B == 0) return FGNN_OK;
+    if (ws_bytes < carve(g, B, nullptr, nullptr) || !workspace) return fgnn_fail(FGNN_ERR_ARG, "workspace too small");
+    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Workspace ws;
+    carve(g, B, workspace, &ws);
+    const int n = g->d.n;
+    int rc;
+    // decoders[0] on the constant channel LLR (feedback_gnn.py:311-313,321)
+    rc = fgnn_bp4_decode_impl(g, cn_types[0], iters[0], factors[0], nullptr, llr_const, synd_x, synd_z, B, nullptr, nullptr,
+                              ws.llr_a, x_hat, z_hat, ws.xlogit, ws.zlogit, nullptr, nullptr, nullptr, stream);
+    if (rc) return rc;
+    const int blk = (B + 255) / 256;
+    if (num_layers > 1) hipLaunchKernelGGL(fill_u8, dim3(blk), dim3(256), 0, st, ws.errors, (uint8_t)1, B);  // (:322)
+    if (rounds) FGNN_HIP_CHECK(hipMemsetAsync(rounds, 0, (size_t)B, st));
+    for (int i = 1; i < num_layers; ++i) {
+        rc = fgnn_flag_update(g, x_hat, z_hat, synd_x, synd_z, B, ws.errors, stream);  // (:324-330)
+        if (rc) return rc;
+        if (rounds) hipLaunchKernelGGL(rounds_add, dim3(blk), dim3(256), 0, st, ws.errors, rounds, B);
+        int nact = B;
+        const int* index = nullptr;
+        if (compact) {
+            FGNN_HIP_CHECK(hipMemsetAsync(ws.count, 0, sizeof(int), st));
+            hipLaunchKernelGGL(compact_kernel, dim3(blk), dim3(256), 0, st, ws.errors, B, ws.index, ws.count);
+            FGNN_HIP_CHECK(hipMemcpyAsync(&nact, ws.count, sizeof(int), hipMemcpyDeviceToHost, st));
+            FGNN_HIP_CHECK(hipStreamSynchronize(st));
+            index = ws.index;
+            if (nact == 0) break;
+        }
+        if (!weights[i - 1]) return fgnn_fail(FGNN_ERR_ARG, "weights handle is NULL");
+        // feedbacks[i-1]((h_vn, logit_hz_perp, logit_hx_perp, ...)) (:333-335): the GNN's logit_hx is the
+        // soft syndrome of the hx rows = z_logit in stage-one mode; logit_hz = x_logit.
+        rc = fgnn_feedback_gnn_impl(g, weights[i - 1], ws.llr_a, ws.zlogit, ws.xlogit, synd_x, synd_z, nact, ws.llr_b, index,
+                                    stream);
+        if (rc) return rc;
+        rc = fgnn_bp4_decode_impl(g, cn_types[i], iters[i], factors[i], ws.llr_b, 0.0f, synd_x, synd_z, nact, nullptr, nullptr,
+                                  ws.llr_a, ws.x_upd, ws.z_upd, ws.xlogit, ws.zlogit, nullptr, nullptr, index, stream);  // (:336)
+        if (rc) return rc;
+        rc = fgnn_merge(ws.errors, ws.x_upd, ws.z_upd, B, n, x_hat, z_hat, stream);  // (:339-340)
+        if (rc) return rc;
+    }
+    if (llr_final)
+        FGNN_HIP_CHECK(hipMemcpyAsync(llr_final, ws.llr_a, sizeof(float) * 3 * (size_t)n * B, hipMemcpyDeviceToDevice, st));
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}

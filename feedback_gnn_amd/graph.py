@@ -1,0 +1,256 @@
+"""Device-resident Tanner graphs of a CSS code and thin torch-tensor wrappers over the C ABI.
+
+`TannerGraph` owns one `fgnn_graph` handle (include/fgnn.h).  PyTorch-ROCm is used only for
+device memory and streams: every method takes/returns torch tensors that live on the graph's
+device, passes their `data_ptr()` and the current HIP stream to the library, and never touches
+the data on the host.  Layouts are the library's codeword-major ones (fgnn.h "Conventions").
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CN_TYPES, check
+
+
+def _coo(mat):
+    r, c = np.nonzero(np.asarray(mat))
+    return np.ascontiguousarray(r, dtype=np.int32), np.ascontiguousarray(c, dtype=np.int32)
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class GnnWeights:
+    """Device copy of one feedback GNN's 12 weight arrays (fgnn_weights)."""
+
+    def __init__(self, arrays, device):
+        arrays = [np.ascontiguousarray(a, dtype=np.float32) for a in arrays]
+        shapes = [(40, 3), (3,), (4, 40), (40,), (40, 20), (20,), (4, 40), (40,), (40, 20), (20,), (43, 40), (40,)]
+        if [a.shape for a in arrays] != shapes:
+            raise ValueError(f"feedback-GNN weights must have shapes {shapes}, got {[a.shape for a in arrays]}")
+        self.arrays = arrays
+        self.device = torch.device(device)
+        ptrs = (C.c_void_p * 12)(*[a.ctypes.data for a in arrays])
+        h = C.c_void_p()
+        check(_lib.lib().fgnn_weights_create(ptrs, self.device.index or 0, C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.lib().fgnn_weights_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class TannerGraph:
+    """hx/hz Tanner graphs + soft-syndrome row sets + hx_perp/hz_perp of one CSS code on one GPU.
+
+    stage_one=True installs pcm_x_perp = hz, pcm_z_perp = hx as the soft-syndrome rows
+    (reference decoding_q.py:35-37), otherwise code.hx_perp / code.hz_perp (:33-34).
+    """
+
+    def __init__(self, code, stage_one=True, device=None):
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.FgnnError("the BP4/feedback-GNN decoder runs on a HIP device only (no CPU fallback)")
+        L = _lib.lib()
+        self.code = code
+        hx, hz = np.asarray(code.hx), np.asarray(code.hz)
+        self.n = int(hx.shape[1])
+        self.m_x, self.m_z = int(hx.shape[0]), int(hz.shape[0])
+        rx, cx = _coo(hx)
+        rz, cz = _coo(hz)
+        self.E_x, self.E_z = len(rx), len(rz)
+        h = C.c_void_p()
+        check(L.fgnn_graph_create(self.n, self.m_x, self.m_z, self.E_x, _np_ptr(rx), _np_ptr(cx), self.E_z, _np_ptr(rz),
+                                  _np_ptr(cz), self.device.index or 0, C.byref(h)))
+        self.handle = h
+        self.stage_one = bool(stage_one)
+        xp, zp = (hz, hx) if stage_one else (np.asarray(code.hx_perp), np.asarray(code.hz_perp))
+        self.rows_xp, self.rows_zp = int(xp.shape[0]), int(zp.shape[0])
+        self.rows_hxp, self.rows_hzp = int(code.hx_perp.shape[0]), int(code.hz_perp.shape[0])
+        for which, mat in ((0, xp), (1, zp), (2, code.hx_perp), (3, code.hz_perp)):
+            r, c = _coo(mat)
+            check(L.fgnn_graph_set_rows(self.handle, which, int(np.asarray(mat).shape[0]), len(r), _np_ptr(r), _np_ptr(c)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.lib().fgnn_graph_destroy(self.handle)
+        except Exception:
+            pass
+
+    # ---- introspection ------------------------------------------------------------------------
+    def info(self):
+        buf = (C.c_int32 * 16)()
+        check(_lib.lib().fgnn_graph_info(self.handle, buf))
+        keys = ("n", "m_x", "m_z", "E_x", "E_z", "threads_per_codeword", "codewords_per_block", "lds_bytes_per_block",
+                "regular", "device", "dv_x", "dv_z", "dc")
+        return dict(zip(keys, list(buf)))
+
+    def set_launch(self, threads_per_codeword=0, codewords_per_block=0):
+        check(_lib.lib().fgnn_graph_set_launch(self.handle, int(threads_per_codeword), int(codewords_per_block)))
+
+    def edges(self, side):
+        """Canonical (qubit, check)-sorted edge list of hx (side 0) or hz (side 1): (chk, var)."""
+        E = self.E_x if side == 0 else self.E_z
+        chk = np.empty(E, np.int32)
+        var = np.empty(E, np.int32)
+        check(_lib.lib().fgnn_graph_edges(self.handle, side, _np_ptr(chk), _np_ptr(var)))
+        return chk, var
+
+    # ---- helpers ----------------------------------------------------------------------------------
+    def _chk(self, t, shape, dtype, name):
+        if t.device != self.device:
+            raise ValueError(f"{name} must live on {self.device}, got {t.device}")
+        if t.dtype != dtype:
+            raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t.contiguous()
+
+    def _new(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    # ---- QLDPCBPDecoder.call ---------------------------------------------------------------------
+    def bp4_decode(self, synd_x, synd_z, num_iter, cn_type="boxplus-phi", factor=1.0, llr_ch=None, llr_const=0.0,
+                   msg_init=None, return_msgs=False, want_logits=True):
+        if cn_type not in CN_TYPES:
+            raise ValueError("Unknown node type.")
+        B = int(synd_x.shape[0])
+        synd_x = self._chk(synd_x, (B, self.m_x), torch.uint8, "synd_x")
+        synd_z = self._chk(synd_z, (B, self.m_z), torch.uint8, "synd_z")
+        if llr_ch is not None:
+            llr_ch = self._chk(llr_ch, (B, 3, self.n), torch.float32, "llr_ch")
+        mix = miz = None
+        if msg_init is not None:
+            mix = self._chk(msg_init[0], (B, self.E_x), torch.float32, "msg_init_x")
+            miz = self._chk(msg_init[1], (B, self.E_z), torch.float32, "msg_init_z")
+        llr = self._new((B, 3, self.n), torch.float32)
+        xh = self._new((B, self.n), torch.uint8)
+        zh = self._new((B, self.n), torch.uint8)
+        xl = self._new((B, self.rows_xp), torch.float32) if want_logits else None
+        zl = self._new((B, self.rows_zp), torch.float32) if want_logits else None
+        mox = self._new((B, self.E_x), torch.float32) if return_msgs else None
+        moz = self._new((B, self.E_z), torch.float32) if return_msgs else None
+        check(_lib.lib().fgnn_bp4_decode(self.handle, CN_TYPES[cn_type], int(num_iter), float(factor), _ptr(llr_ch),
+                                         float(llr_const), _ptr(synd_x), _ptr(synd_z), B, _ptr(mix), _ptr(miz), _ptr(llr),
+                                         _ptr(xh), _ptr(zh), _ptr(xl), _ptr(zl), _ptr(mox), _ptr(moz), _stream(self.device)))
+        out = dict(llr=llr, x_hat=xh, z_hat=zh, x_logit=xl, z_logit=zl)
+        if return_msgs:
+            out["msg_x"], out["msg_z"] = mox, moz
+        return out
+
+    # ---- Feedback_GNN.call -------------------------------------------------------------------------
+    def feedback_gnn(self, weights, llr, logit_hx, logit_hz, synd_x, synd_z):
+        B = int(llr.shape[0])
+        llr = self._chk(llr, (B, 3, self.n), torch.float32, "llr")
+        logit_hx = self._chk(logit_hx, (B, self.m_x), torch.float32, "logit_hx")
+        logit_hz = self._chk(logit_hz, (B, self.m_z), torch.float32, "logit_hz")
+        synd_x = self._chk(synd_x, (B, self.m_x), torch.uint8, "synd_x")
+        synd_z = self._chk(synd_z, (B, self.m_z), torch.uint8, "synd_z")
+        out = self._new((B, 3, self.n), torch.float32)
+        check(_lib.lib().fgnn_feedback_gnn(self.handle, weights.handle, _ptr(llr), _ptr(logit_hx), _ptr(logit_hz),
+                                           _ptr(synd_x), _ptr(synd_z), B, _ptr(out), _stream(self.device)))
+        return out
+
+    # ---- channel / syndromes / flags / residual ---------------------------------------------------------
+    def pauli_noise(self, seed, p, first_sample, B):
+        ex = self._new((B, self.n), torch.uint8)
+        ez = self._new((B, self.n), torch.uint8)
+        check(_lib.lib().fgnn_pauli_noise(int(seed), float(np.float32(p)), int(first_sample), B, self.n, _ptr(ex), _ptr(ez),
+                                          _stream(self.device)))
+        return ex, ez
+
+    def syndrome(self, ex, ez):
+        B = int(ex.shape[0])
+        ex = self._chk(ex, (B, self.n), torch.uint8, "noise_x")
+        ez = self._chk(ez, (B, self.n), torch.uint8, "noise_z")
+        sx = self._new((B, self.m_x), torch.uint8)
+        sz = self._new((B, self.m_z), torch.uint8)
+        check(_lib.lib().fgnn_syndrome(self.handle, _ptr(ex), _ptr(ez), B, _ptr(sx), _ptr(sz), _stream(self.device)))
+        return sx, sz
+
+    def flag_update(self, x_hat, z_hat, synd_x, synd_z, errors):
+        B = int(x_hat.shape[0])
+        check(_lib.lib().fgnn_flag_update(self.handle, _ptr(self._chk(x_hat, (B, self.n), torch.uint8, "x_hat")),
+                                          _ptr(self._chk(z_hat, (B, self.n), torch.uint8, "z_hat")),
+                                          _ptr(self._chk(synd_x, (B, self.m_x), torch.uint8, "synd_x")),
+                                          _ptr(self._chk(synd_z, (B, self.m_z), torch.uint8, "synd_z")), B,
+                                          _ptr(self._chk(errors, (B,), torch.uint8, "errors")), _stream(self.device)))
+        return errors
+
+    def merge(self, errors, x_upd, z_upd, x_hat, z_hat):
+        B = int(x_hat.shape[0])
+        for t, nm in ((x_upd, "x_upd"), (z_upd, "z_upd"), (x_hat, "x_hat"), (z_hat, "z_hat")):
+            self._chk(t, (B, self.n), torch.uint8, nm)
+        check(_lib.lib().fgnn_merge(_ptr(errors), _ptr(x_upd), _ptr(z_upd), B, self.n, _ptr(x_hat), _ptr(z_hat),
+                                    _stream(self.device)))
+
+    def residual(self, ex, ez, x_hat, z_hat, want_arrays=True):
+        B = int(ex.shape[0])
+        for t, nm in ((ex, "noise_x"), (ez, "noise_z"), (x_hat, "x_hat"), (z_hat, "z_hat")):
+            self._chk(t, (B, self.n), torch.uint8, nm)
+        s_hat = self._new((B, self.m_z + self.m_x), torch.uint8) if want_arrays else None
+        ls_hat = self._new((B, self.rows_hxp + self.rows_hzp), torch.uint8) if want_arrays else None
+        flags = self._new((B,), torch.uint8)
+        check(_lib.lib().fgnn_residual(self.handle, _ptr(ex), _ptr(ez), _ptr(x_hat), _ptr(z_hat), B, _ptr(s_hat), _ptr(ls_hat),
+                                       _ptr(flags), _stream(self.device)))
+        return s_hat, ls_hat, flags
+
+    def count_flags(self, flags, counts):
+        """counts (uint64/int64 [3] on device) += (#flagged, #block errors, #samples)."""
+        check(_lib.lib().fgnn_count_flags(_ptr(flags), int(flags.shape[0]), _ptr(counts), _stream(self.device)))
+        return counts
+
+    # ---- Sandwich body -----------------------------------------------------------------------------------
+    def sandwich_workspace(self, B):
+        nbytes = _lib.lib().fgnn_sandwich_workspace_bytes(self.handle, int(B))
+        return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+
+    def sandwich_decode(self, synd_x, synd_z, iters, weights_list, llr_const, factors=None, cn_types=None, compact=False,
+                        workspace=None, return_llr=False, return_rounds=False):
+        num_layers = len(iters)
+        if len(weights_list) != num_layers - 1:
+            raise ValueError("need num_layers-1 feedback GNNs")
+        if not self.stage_one:
+            raise ValueError("the sandwich needs a stage_one graph")
+        factors = [1.0] * num_layers if factors is None else list(factors)
+        cn_types = ["boxplus-phi"] * num_layers if cn_types is None else list(cn_types)
+        it = np.asarray(iters, dtype=np.int32)
+        fa = np.asarray(factors, dtype=np.float32)
+        ct = np.asarray([CN_TYPES[c] for c in cn_types], dtype=np.int32)
+        wh = (C.c_void_p * max(1, num_layers - 1))(*[w.handle for w in weights_list])
+        B = int(synd_x.shape[0])
+        synd_x = self._chk(synd_x, (B, self.m_x), torch.uint8, "synd_x")
+        synd_z = self._chk(synd_z, (B, self.m_z), torch.uint8, "synd_z")
+        if workspace is None:
+            workspace = self.sandwich_workspace(B)
+        xh = self._new((B, self.n), torch.uint8)
+        zh = self._new((B, self.n), torch.uint8)
+        llr = self._new((B, 3, self.n), torch.float32) if return_llr else None
+        rounds = self._new((B,), torch.uint8) if return_rounds else None
+        check(_lib.lib().fgnn_sandwich_decode(self.handle, num_layers, _np_ptr(it), _np_ptr(fa), _np_ptr(ct), wh,
+                                              float(llr_const), _ptr(synd_x), _ptr(synd_z), B, int(bool(compact)), _ptr(xh),
+                                              _ptr(zh), _ptr(llr), _ptr(rounds), _ptr(workspace), workspace.numel(),
+                                              _stream(self.device)))
+        out = dict(x_hat=xh, z_hat=zh)
+        if return_llr:
+            out["llr"] = llr
+        if return_rounds:
+            out["rounds"] = rounds
+        return out

@@ -1,0 +1,130 @@
+/* fgnn.h — C ABI of the MI355X-native BP4 + feedback-GNN decoder (libfgnn_hip.so).
+ *
+ * The reference (gongaa/Feedback-GNN, a Sionna/TensorFlow fork) has no FFI: its boundary is the
+ * Keras-Layer call contract.  This header is the C boundary placed directly beneath the Python
+ * classes that keep the reference's names (feedback_gnn_amd/decoding_q.py, feedback_gnn.py).
+ * Each entry point cites the reference code it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - plain C types only; every data pointer is a DEVICE pointer (HIP) unless marked "host";
+ *   - the caller owns all buffers; the library owns only the immutable tables inside fgnn_graph /
+ *     fgnn_weights; no allocation, no synchronisation on the hot path: all work is enqueued on
+ *     `stream` (a hipStream_t passed as void*);
+ *   - every per-codeword array is codeword-major ("batch first"), contiguous:
+ *       llr      float32 [B,3,n]   planes (x,y,z): L_E = log(P(I)/P(E)), positive = no error
+ *       synd_x   uint8   [B,m_x]   hx * noise_z mod 2          synd_z uint8 [B,m_z]  hz * noise_x mod 2
+ *       x_hat    uint8   [B,n]     z_hat uint8 [B,n]
+ *       messages float32 [B,E]     canonical edge order = sorted by (qubit, check)
+ *   - return value 0 = OK, negative = error; text via fgnn_last_error().
+ */
+#ifndef FGNN_H
+#define FGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fgnn_graph fgnn_graph;     /* Tanner graphs + row sets of one CSS code, on one device */
+typedef struct fgnn_weights fgnn_weights; /* one feedback GNN's 3 923 parameters, on one device */
+
+enum { FGNN_CN_BOXPLUS = 0, FGNN_CN_BOXPLUS_PHI = 1, FGNN_CN_MINSUM = 2 }; /* decoding_q.py:97-107 */
+enum { FGNN_ROWS_X_LOGIT = 0, FGNN_ROWS_Z_LOGIT = 1, FGNN_ROWS_HX_PERP = 2, FGNN_ROWS_HZ_PERP = 3 };
+
+enum {
+    FGNN_OK = 0,
+    FGNN_ERR_ARG = -1,     /* shape / value rejected (the Python shim raises ValueError) */
+    FGNN_ERR_HIP = -2,     /* a HIP runtime call failed */
+    FGNN_ERR_STATE = -3,   /* e.g. row set missing */
+    FGNN_ERR_NOMEM = -4
+};
+
+const char* fgnn_last_error(void);
+int fgnn_version(void);
+
+/* QLDPCBPDecoder.__init__ edge tables, decoding_q.py:53-94: built here from COO lists of hx and hz
+ * (host pointers, any order).  `device` = HIP device ordinal. */
+int fgnn_graph_create(int n, int m_x, int m_z, int nnz_x, const int32_t* chk_x, const int32_t* var_x, int nnz_z,
+                      const int32_t* chk_z, const int32_t* var_z, int device, fgnn_graph** out);
+void fgnn_graph_destroy(fgnn_graph* g);
+
+/* Extra binary row sets as COO (host pointers):
+ *   FGNN_ROWS_X_LOGIT / Z_LOGIT : pcm_x_perp / pcm_z_perp of decoding_q.py:33-37,93-94
+ *                                 (hz / hx when stage_one or stage_two, else hx_perp / hz_perp);
+ *   FGNN_ROWS_HX_PERP / HZ_PERP : code.hx_perp / code.hz_perp for the residual check,
+ *                                 feedback_gnn.py:352-353. */
+int fgnn_graph_set_rows(fgnn_graph* g, int which, int rows, int nnz, const int32_t* row, const int32_t* col);
+
+/* Launch geometry of the LDS-resident kernels: threads per codeword and codewords per workgroup.
+ * 0 = keep the built-in heuristic.  (No reference equivalent: XLA picks its own launch shapes.) */
+int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords_per_block);
+/* info[0..9] = n, m_x, m_z, E_x, E_z, threads_per_codeword, codewords_per_block, lds_bytes_per_block,
+ *              regular(0/1), device */
+int fgnn_graph_info(const fgnn_graph* g, int32_t info[16]);
+/* canonical (qubit, check)-sorted edge lists, host output: chk[E_s], var[E_s] for side 0 (hx) / 1 (hz) */
+int fgnn_graph_edges(const fgnn_graph* g, int side, int32_t* chk, int32_t* var);
+
+/* QLDPCBPDecoder.call, decoding_q.py:661-797 (flooding BP4, num_iter iterations, then marginals,
+ * hard decision :783-790 and soft syndrome cal_logit :455-471).
+ *   llr_ch       [B,3,n] or NULL: all three channel LLRs = llr_const (feedback_gnn.py:311-313)
+ *   msg_init_*   [B,E_x]/[B,E_z] or NULL (= zeros, :726-727)        msg_out_* optional
+ *   llr_out      [B,3,n] marginals (llrx, llry, llrz of :777)       x_hat,z_hat [B,n]
+ *   x_logit      [B,rows(X_LOGIT)]  z_logit [B,rows(Z_LOGIT)]  (either may be NULL)
+ */
+int fgnn_bp4_decode(const fgnn_graph* g, int cn_type, int num_iter, float normalization_factor, const float* llr_ch,
+                    float llr_const, const uint8_t* synd_x, const uint8_t* synd_z, int B, const float* msg_init_x,
+                    const float* msg_init_z, float* llr_out, uint8_t* x_hat, uint8_t* z_hat, float* x_logit,
+                    float* z_logit, float* msg_out_x, float* msg_out_z, void* stream);
+
+/* load_weights, gnn.py:774-791: 12 host arrays in the reference's file order
+ * [W_out(40,3), b_out(3), Wx1(4,40), bx1(40), Wx2(40,20), bx2(20), Wz1, bz1, Wz2, bz2, We(43,40), be(40)]. */
+int fgnn_weights_create(const float* const host_arrays[12], int device, fgnn_weights** out);
+void fgnn_weights_destroy(fgnn_weights* w);
+
+/* Feedback_GNN.call, feedback_gnn.py:161-188 (reduce_op="mean", activation="tanh", 2-layer MLPs):
+ *   llr [B,3,n] = h_vn planes (llrx, llry, llrz);  logit_hx [B,m_x], logit_hz [B,m_z] soft syndromes
+ *   of the hx / hz rows;  out [B,3,n] = new channel LLRs for the next BP run. */
+int fgnn_feedback_gnn(const fgnn_graph* g, const fgnn_weights* w, const float* llr, const float* logit_hx,
+                      const float* logit_hz, const uint8_t* synd_x, const uint8_t* synd_z, int B, float* out,
+                      void* stream);
+
+/* Pauli.call (non-wt branch), sionna/channel/pauli.py:98-108 with px=pz=2p/3, py=p/3
+ * (feedback_gnn.py:298): Philox4x32-10 stream keyed by (seed, first_sample + b). */
+int fgnn_pauli_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, uint8_t* noise_x, uint8_t* noise_z,
+                     void* stream);
+/* syndrome_x = hx noise_z, syndrome_z = hz noise_x (mod 2), feedback_gnn.py:305-309. */
+int fgnn_syndrome(const fgnn_graph* g, const uint8_t* noise_x, const uint8_t* noise_z, int B, uint8_t* synd_x,
+                  uint8_t* synd_z, void* stream);
+/* errors[b] &= (syndrome of (x_hat,z_hat) != (synd_z, synd_x)), feedback_gnn.py:324-330. */
+int fgnn_flag_update(const fgnn_graph* g, const uint8_t* x_hat, const uint8_t* z_hat, const uint8_t* synd_x,
+                     const uint8_t* synd_z, int B, uint8_t* errors, void* stream);
+/* x_hat[b], z_hat[b] <- x_upd[b], z_upd[b] where errors[b], feedback_gnn.py:339-340. */
+int fgnn_merge(const uint8_t* errors, const uint8_t* x_upd, const uint8_t* z_upd, int B, int n, uint8_t* x_hat,
+               uint8_t* z_hat, void* stream);
+/* Residual check, feedback_gnn.py:343-361: s_hat [B,m_z+m_x] = [hz xd ; hx zd], ls_hat
+ * [B,rows(hx_perp)+rows(hz_perp)] (either may be NULL), flags[b] bit0 = any(s_hat), bit1 = any(ls_hat)
+ * (= what count_block_errors sees, sionna/utils/metrics.py:221-223 via misc.py:649-651). */
+int fgnn_residual(const fgnn_graph* g, const uint8_t* noise_x, const uint8_t* noise_z, const uint8_t* x_hat,
+                  const uint8_t* z_hat, int B, uint8_t* s_hat, uint8_t* ls_hat, uint8_t* flags, void* stream);
+/* counts[0] += #flagged, counts[1] += #block errors, counts[2] += B (device uint64[3]), misc.py:649-669. */
+int fgnn_count_flags(const uint8_t* flags, int B, uint64_t* counts, void* stream);
+
+/* Sandwich_BP_GNN_Evaluation_Model.call, feedback_gnn.py:293-361, from the syndromes on:
+ * decoder 0, then for i = 1..num_layers-1: flag update, GNN i-1, decoder i, masked merge.
+ * iters/factors/cn_types: host arrays [num_layers]; weights: host array of num_layers-1 handles.
+ * Needs the logit row sets to be (hz, hx) ("stage_one").  compact != 0 runs the GNN/BP rounds only on
+ * the samples still in `errors` (same x_hat/z_hat, fewer FLOPs; llr_final then holds the last marginals
+ * computed for each sample).  rounds[b] (optional) = rounds in which sample b was still in `errors`. */
+size_t fgnn_sandwich_workspace_bytes(const fgnn_graph* g, int B);
+int fgnn_sandwich_decode(const fgnn_graph* g, int num_layers, const int32_t* iters, const float* factors,
+                         const int32_t* cn_types, const fgnn_weights* const* weights, float llr_const,
+                         const uint8_t* synd_x, const uint8_t* synd_z, int B, int compact, uint8_t* x_hat,
+                         uint8_t* z_hat, float* llr_final, uint8_t* rounds, void* workspace, size_t ws_bytes,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FGNN_H */

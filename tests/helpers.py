@@ -1,0 +1,67 @@
+"""Shared helpers for the test-suite: code zoo, golden fixtures, oracle/GPU graph caches."""
+import functools
+import os
+
+import numpy as np
+
+from feedback_gnn_amd import codes_q as cq
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CODE_MAKERS = {
+    "steane": lambda: cq.css_code(cq.hamming_code(3), cq.hamming_code(3), name="Steane_n7_k1_d3"),
+    "rsurf3": lambda: cq.create_rotated_surface_codes(3),
+    "rsurf5": lambda: cq.create_rotated_surface_codes(5),
+    "surf3": lambda: cq.create_surface_codes(3),
+    "toric4": lambda: cq.create_checkerboard_toric_codes(4),
+    "gb48": lambda: cq.create_generalized_bicycle_codes(24, [0, 2, 8, 15], [0, 2, 12, 17], name="GB_n48_k6_d8"),
+    "gb126": lambda: cq.create_generalized_bicycle_codes(63, [0, 1, 14, 16, 22], [0, 3, 13, 20, 42]),
+    "hp_c7": lambda: cq.hypergraph_product(cq.create_circulant_matrix(7, [0, 1, 3]), cq.create_circulant_matrix(7, [0, 1, 3])),
+    "ibm72": lambda: cq.create_bivariate_QC_codes(6, 6, [3], [1, 2], [1, 2], [3]),
+    "ghp882": lambda: cq.create_QC_GHP_codes(63, cq.create_cyclic_permuting_matrix(7, [27, 54, 0]), [0, 1, 6]),
+    "ghp1270": lambda: cq.create_QC_GHP_codes(
+        127, np.array([[0, -1, 51, 52, -1], [-1, 0, -1, 111, 20], [0, -1, 98, -1, 122], [0, 80, -1, 119, -1],
+                       [-1, 0, 5, -1, 106]]), [0, 1, 7], name="GHP_n1270_k28"),
+}
+
+WEIGHTS_882 = "feedback_GNN_n882_k24_wt_4_60_iter_64_16_mixed.npz"
+WEIGHTS_1270 = "feedback_GNN_n1270_k28_wt_10_80_iter_64_16_mixed.npz"
+
+
+@functools.lru_cache(maxsize=None)
+def code(name):
+    return CODE_MAKERS[name]()
+
+
+@functools.lru_cache(maxsize=None)
+def oracle_graph(name, stage_one=True):
+    from oracle.oracle import OracleGraph
+    return OracleGraph(code(name), stage_one=stage_one)
+
+
+@functools.lru_cache(maxsize=None)
+def gpu_graph(name, stage_one=True):
+    from feedback_gnn_amd.graph import TannerGraph
+    return TannerGraph(code(name), stage_one=stage_one)
+
+
+def llr_const(p0):
+    """log(3(1-p0)/p0) in float32 arithmetic, feedback_gnn.py:312."""
+    p0 = np.float32(p0)
+    return float(np.log(np.float32(3.0) * (np.float32(1.0) - p0) / p0, dtype=np.float32))
+
+
+def golden_codes():
+    return np.load(os.path.join(GOLDEN, "codes.npz"))
+
+
+def unpack(g, key, attr):
+    sh = g[f"{key}/{attr}_shape"]
+    if sh[0] == 0:
+        return np.zeros(sh, dtype=np.uint8)
+    return np.unpackbits(g[f"{key}/{attr}"], axis=1)[:, :sh[1]]
+
+
+def to_gpu(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()

@@ -1,0 +1,149 @@
+"""GPU parity tests: every HIP entry point of libfgnn_hip.so against the CPU oracle.
+
+The kernels and the oracle share one float32 operation sequence (fgnn_math.h, canonical summation
+order), so the bar here is EXACT equality of every float and every decision — for converged and
+non-converged samples alike — not a tolerance.  (The oracle itself is pinned to the reference by
+tests/test_oracle_kat.py within the north-star tolerance of 1e-4.)
+"""
+import numpy as np
+import pytest
+
+from helpers import WEIGHTS_882, WEIGHTS_1270, code, gpu_graph, llr_const, oracle_graph, to_gpu
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5EED
+
+
+def _noise_and_syndromes(name, p, B, first=0):
+    og, gg = oracle_graph(name), gpu_graph(name)
+    ex, ez = og.pauli_noise(SEED, p, first, B)
+    gx, gz = gg.pauli_noise(SEED, p, first, B)
+    assert np.array_equal(ex, gx.cpu().numpy()) and np.array_equal(ez, gz.cpu().numpy())
+    sx, sz = og.syndrome(ex, ez)
+    tx, tz = gg.syndrome(gx, gz)
+    assert np.array_equal(sx, tx.cpu().numpy()) and np.array_equal(sz, tz.cpu().numpy())
+    return (ex, ez, sx, sz), (gx, gz, tx, tz)
+
+
+def _assert_bp_equal(o, g, what=""):
+    for k in ("llr", "x_logit", "z_logit", "msg_x", "msg_z"):
+        if k in o and o[k] is not None and g.get(k) is not None:
+            a, b = o[k], g[k].cpu().numpy()
+            assert np.array_equal(a, b), f"{what} {k}: max|d|={np.abs(a - b).max()} at {np.argwhere(a != b)[:3]}"
+    for k in ("x_hat", "z_hat"):
+        assert np.array_equal(o[k], g[k].cpu().numpy()), f"{what} {k}"
+
+
+@pytest.mark.parametrize("name,p", [("ghp882", 0.05), ("ghp882", 0.10), ("ghp1270", 0.08)])
+@pytest.mark.parametrize("iters", [1, 2, 16, 64])
+def test_bp4_phi_bit_exact(name, p, iters):
+    B = 48
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, p, B)
+    L0 = llr_const(0.05)
+    o = oracle_graph(name).bp4_decode(sx, sz, iters, "boxplus-phi", 1.0, llr_const=L0, return_msgs=True)
+    g = gpu_graph(name).bp4_decode(tx, tz, iters, "boxplus-phi", 1.0, llr_const=L0, return_msgs=True)
+    _assert_bp_equal(o, g, f"{name} p={p} it={iters}")
+
+
+@pytest.mark.parametrize("cn_type,factor", [("minsum", 0.625), ("boxplus", 0.625), ("boxplus-phi", 0.8)])
+def test_bp4_cn_variants_bit_exact(cn_type, factor):
+    B = 40
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes("ghp882", 0.07, B, first=1000)
+    L0 = llr_const(0.3)
+    o = oracle_graph("ghp882").bp4_decode(sx, sz, 24, cn_type, factor, llr_const=L0, return_msgs=True)
+    g = gpu_graph("ghp882").bp4_decode(tx, tz, 24, cn_type, factor, llr_const=L0, return_msgs=True)
+    _assert_bp_equal(o, g, cn_type)
+
+
+@pytest.mark.parametrize("name", ["steane", "rsurf3", "rsurf5", "surf3", "toric4", "gb48", "gb126", "hp_c7", "ibm72"])
+@pytest.mark.parametrize("cn_type", ["boxplus-phi", "minsum", "boxplus"])
+def test_bp4_small_and_irregular_codes(name, cn_type):
+    B = 77  # not a multiple of codewords-per-block: exercises the padded last workgroup
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, 0.08, B)
+    L0 = llr_const(0.05)
+    o = oracle_graph(name).bp4_decode(sx, sz, 12, cn_type, 0.8, llr_const=L0, return_msgs=True)
+    g = gpu_graph(name).bp4_decode(tx, tz, 12, cn_type, 0.8, llr_const=L0, return_msgs=True)
+    _assert_bp_equal(o, g, f"{name} {cn_type}")
+
+
+def test_bp4_message_step_with_edge_cases():
+    """One iteration from crafted c->v messages: exact zeros, +-20, duplicates, tiny values, huge values."""
+    name, B = "ghp882", 16
+    og, gg = oracle_graph(name), gpu_graph(name)
+    rng = np.random.RandomState(1)
+    mx = rng.uniform(-10, 10, size=(B, og.E_x)).astype(np.float32)
+    mz = rng.uniform(-10, 10, size=(B, og.E_z)).astype(np.float32)
+    specials = np.array([0.0, -0.0, 20.0, -20.0, 8.5e-8, -8.5e-8, 1e-9, 16.635532, -16.635532, 37.5, -60.0, 1e-3],
+                        dtype=np.float32)
+    mx[1::2, ::7] = specials[rng.randint(0, len(specials), size=mx[1::2, ::7].shape)]
+    mz[1::2, ::5] = specials[rng.randint(0, len(specials), size=mz[1::2, ::5].shape)]
+    mx[2] = 0.0
+    mz[2] = 0.0
+    mx[3] = 3.25  # all equal -> duplicate minima everywhere
+    mz[3] = -3.25
+    sx = rng.randint(0, 2, size=(B, og.m_x)).astype(np.uint8)
+    sz = rng.randint(0, 2, size=(B, og.m_z)).astype(np.uint8)
+    llr = rng.uniform(0.2, 6.0, size=(B, 3, og.n)).astype(np.float32)
+    for cn_type in ("boxplus-phi", "minsum", "boxplus"):
+        for iters in (1, 3):
+            o = og.bp4_decode(sx, sz, iters, cn_type, 0.9, llr_ch=llr, msg_init=(mx, mz), return_msgs=True)
+            g = gg.bp4_decode(to_gpu(sx), to_gpu(sz), iters, cn_type, 0.9, llr_ch=to_gpu(llr),
+                              msg_init=(to_gpu(mx), to_gpu(mz)), return_msgs=True)
+            _assert_bp_equal(o, g, f"step {cn_type} {iters}")
+
+
+def test_bp4_non_stage_one_logits():
+    """Soft syndrome over the dense hx_perp/hz_perp rows (decoding_q.py:33-34 when not stage_one)."""
+    name, B = "gb48", 33
+    og, gg = oracle_graph(name, False), gpu_graph(name, False)
+    ex, ez = og.pauli_noise(SEED, 0.06, 0, B)
+    sx, sz = og.syndrome(ex, ez)
+    o = og.bp4_decode(sx, sz, 10, "boxplus-phi", 0.625, llr_const=llr_const(0.1))
+    g = gg.bp4_decode(to_gpu(sx), to_gpu(sz), 10, "boxplus-phi", 0.625, llr_const=llr_const(0.1))
+    assert o["x_logit"].shape[1] == code(name).hx_perp.shape[0]
+    _assert_bp_equal(o, g, "non-stage-one")
+
+
+@pytest.mark.parametrize("name,wfile,p", [("ghp882", WEIGHTS_882, 0.10), ("ghp1270", WEIGHTS_1270, 0.09)])
+def test_feedback_gnn_bit_exact(name, wfile, p):
+    from feedback_gnn_amd.graph import GnnWeights
+    from feedback_gnn_amd.weights_io import read_weight_list
+    B = 24
+    og, gg = oracle_graph(name), gpu_graph(name)
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, p, B)
+    w = read_weight_list(wfile)
+    o = og.bp4_decode(sx, sz, 64, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
+    on = og.feedback_gnn(w, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
+    gw = GnnWeights(w, gg.device)
+    gn = gg.feedback_gnn(gw, to_gpu(o["llr"]), to_gpu(o["z_logit"]), to_gpu(o["x_logit"]), tx, tz).cpu().numpy()
+    assert np.array_equal(on, gn), f"max|d|={np.abs(on - gn).max()}"
+    assert np.isfinite(gn).all()
+
+
+@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("name,wfile,iters,p", [("ghp882", WEIGHTS_882, [64, 16], 0.10),
+                                                ("ghp882", WEIGHTS_882, [64, 16, 16, 16], 0.12),
+                                                ("ghp1270", WEIGHTS_1270, [64, 64], 0.10)])
+def test_sandwich_and_residual_bit_exact(name, wfile, iters, p, compact):
+    from feedback_gnn_amd.graph import GnnWeights
+    from feedback_gnn_amd.weights_io import read_weight_list
+    B = 96
+    og, gg = oracle_graph(name), gpu_graph(name)
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, p, B, first=12345)
+    w = read_weight_list(wfile)
+    gw = GnnWeights(w, gg.device)
+    nl = len(iters)
+    o = og.sandwich_decode(sx, sz, iters, [w] * (nl - 1), llr_const(0.05), return_llr=True)
+    g = gg.sandwich_decode(tx, tz, iters, [gw] * (nl - 1), llr_const(0.05), compact=compact, return_llr=True,
+                           return_rounds=True)
+    assert np.array_equal(o["x_hat"], g["x_hat"].cpu().numpy())
+    assert np.array_equal(o["z_hat"], g["z_hat"].cpu().numpy())
+    assert np.array_equal(o["rounds"], g["rounds"].cpu().numpy())
+    assert o["rounds"].sum() > 0, "test must exercise the feedback rounds"
+    if not compact:
+        assert np.array_equal(o["llr"], g["llr"].cpu().numpy())
+    s0, l0, f0 = og.residual(ex, ez, o["x_hat"], o["z_hat"])
+    s1, l1, f1 = gg.residual(gx, gz, g["x_hat"], g["z_hat"])
+    assert np.array_equal(s0, s1.cpu().numpy()) and np.array_equal(l0, l1.cpu().numpy())
+    assert np.array_equal(f0, f1.cpu().numpy())
