@@ -39,6 +39,8 @@ _SIGNATURES = {
     "fgnn_graph_set_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "fgnn_graph_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fgnn_graph_edges": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "fgnn_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "fgnn_profile_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "fgnn_bp4_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                   C.c_int] + [C.c_void_p] * 10),
     "fgnn_weights_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
@@ -68,6 +70,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise FgnnError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(there is no CPU fallback for the decoder)")
+        # PyTorch-ROCm must be loaded FIRST: the library then binds to the HIP runtime instance torch already
+        # brought into the process (same soname), which is what makes torch's device pointers and streams
+        # valid inside libfgnn_hip.so.  Loading the library before torch would start a second runtime.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)

@@ -314,11 +314,21 @@ int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float n
     size_t lds_bytes = (size_t)per_cw * sizeof(float) * (size_t)L.cpb;
     if (lds_bytes > 160 * 1024) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident kernel");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool prof = g->prof_on && (size_t)(2 * g->prof_n + 1) < g->prof_ev.size();
+    if (prof) FGNN_HIP_CHECK(hipEventRecord(g->prof_ev[2 * g->prof_n], st));
+    int rc;
     switch (cn_type) {
-    case FGNN_CN_BOXPLUS_PHI: return launch_bp4<FGNN_CN_BOXPLUS_PHI>(g, a, L, lds_bytes, st);
-    case FGNN_CN_MINSUM: return launch_bp4<FGNN_CN_MINSUM>(g, a, L, lds_bytes, st);
-    default: return launch_bp4<FGNN_CN_BOXPLUS>(g, a, L, lds_bytes, st);
+    case FGNN_CN_BOXPLUS_PHI: rc = launch_bp4<FGNN_CN_BOXPLUS_PHI>(g, a, L, lds_bytes, st); break;
+    case FGNN_CN_MINSUM: rc = launch_bp4<FGNN_CN_MINSUM>(g, a, L, lds_bytes, st); break;
+    default: rc = launch_bp4<FGNN_CN_BOXPLUS>(g, a, L, lds_bytes, st); break;
     }
+    if (prof && rc == FGNN_OK) {
+        FGNN_HIP_CHECK(hipEventRecord(g->prof_ev[2 * g->prof_n + 1], st));
+        g->prof_iters[g->prof_n] = num_iter;
+        g->prof_batch[g->prof_n] = B;
+        g->prof_n++;
+    }
+    return rc;
 }
 
 extern "C" int fgnn_bp4_decode(const fgnn_graph* g, int cn_type, int num_iter, float normalization_factor,

@@ -173,6 +173,7 @@ extern "C" void fgnn_graph_destroy(fgnn_graph* g)
 {
     if (!g) return;
     (void)hipSetDevice(g->device);
+    for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
     for (void* p : g->allocs) (void)hipFree(p);
     for (auto& r : g->row_alloc)
         for (void* p : r)
@@ -250,5 +251,43 @@ extern "C" int fgnn_graph_edges(const fgnn_graph* g, int side, int32_t* chk, int
     if (!g || side < 0 || side > 1 || !chk || !var) return fgnn_fail(FGNN_ERR_ARG, "bad arguments");
     std::copy(g->h_chk[side].begin(), g->h_chk[side].end(), chk);
     std::copy(g->h_var[side].begin(), g->h_var[side].end(), var);
+    return FGNN_OK;
+}
+
+// Per-launch timing of the BP4 kernel: HIP events recorded on the launch stream immediately before and
+// after each bp4 launch (inside fgnn_bp4_decode and inside fgnn_sandwich_decode), read back afterwards.
+extern "C" int fgnn_profile_enable(fgnn_graph* g, int max_launches)
+{
+    if (!g || max_launches < 0) return fgnn_fail(FGNN_ERR_ARG, "bad profile arguments");
+    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
+    g->prof_ev.clear();
+    g->prof_n = 0;
+    g->prof_on = max_launches > 0;
+    g->prof_iters.assign(max_launches, 0);
+    g->prof_batch.assign(max_launches, 0);
+    for (int i = 0; i < 2 * max_launches; ++i) {
+        hipEvent_t e;
+        FGNN_HIP_CHECK(hipEventCreate(&e));
+        g->prof_ev.push_back(e);
+    }
+    return FGNN_OK;
+}
+
+// ms[i], iters[i], batch[i] for the launches recorded since the last read (host arrays of length cap);
+// waits for the last recorded event; resets the recorder.
+extern "C" int fgnn_profile_read(fgnn_graph* g, float* ms, int32_t* iters, int32_t* batch, int cap, int32_t* count)
+{
+    if (!g || !ms || !iters || !batch || !count) return fgnn_fail(FGNN_ERR_ARG, "NULL argument");
+    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    int n = g->prof_n < cap ? g->prof_n : cap;
+    if (g->prof_n > 0) FGNN_HIP_CHECK(hipEventSynchronize(g->prof_ev[2 * g->prof_n - 1]));
+    for (int i = 0; i < n; ++i) {
+        FGNN_HIP_CHECK(hipEventElapsedTime(&ms[i], g->prof_ev[2 * i], g->prof_ev[2 * i + 1]));
+        iters[i] = g->prof_iters[i];
+        batch[i] = g->prof_batch[i];
+    }
+    *count = n;
+    g->prof_n = 0;
     return FGNN_OK;
 }

@@ -35,6 +35,11 @@ struct fgnn_graph {
     // host copies of the canonical edge lists (fgnn_graph_edges)
     std::vector<int32_t> h_chk[2], h_var[2];
     void* row_alloc[4][2];
+    // optional per-launch timing of the BP4 kernel with HIP events on the launch stream (fgnn_profile_*)
+    mutable bool prof_on = false;
+    mutable int prof_n = 0;
+    mutable std::vector<hipEvent_t> prof_ev;  // 2 per launch
+    mutable std::vector<int> prof_iters, prof_batch;
 };
 
 // Device layout of one feedback GNN (transposed where that makes the scalar loads contiguous).

@@ -1,0 +1,199 @@
+"""Feedback_GNN and the BP/GNN sandwich evaluation model on MI355X.
+
+Drop-ins for `sionna.fec.ldpc.Feedback_GNN` and `Sandwich_BP_GNN_Evaluation_Model`
+(/root/reference sionna/fec/ldpc/feedback_gnn.py:20-188, :232-361) and for the non-weight branch of
+`sionna.channel.Pauli` (sionna/channel/pauli.py:98-108).  All device work goes through
+libfgnn_hip.so (include/fgnn.h); tensors are torch tensors on the HIP device.
+"""
+import numpy as np
+import torch
+
+from .graph import GnnWeights, TannerGraph
+from .weights_io import read_weight_list
+
+_W_SHAPES = [(40, 3), (3,), (4, 40), (40,), (40, 20), (20,), (4, 40), (40,), (40, 20), (20,), (43, 40), (40,)]
+
+
+def _glorot_uniform(rng, shape):
+    lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+class Feedback_GNN:
+    """One CN->VN message-passing layer that maps BP marginals + soft syndromes to new channel LLRs.
+
+    Constructor as feedback_gnn.py:21-28.  The HIP kernel implements the architecture the reference
+    trains and ships (n882.py:45-51): num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2,
+    reduce_op="mean", activation="tanh", use_bias=True; other settings raise NotImplementedError.
+
+    Call: ``G((h_vn[bs,n,3], logit_hx[m_x,bs], logit_hz[m_z,bs], syndrome_x[m_x,bs], syndrome_z[m_z,bs]))``
+    → ``[bs,n,3]`` (new llrx, llry, llrz).
+    """
+
+    def __init__(self, code, num_msg_dims, num_hidden_units, num_mlp_layers, reduce_op="mean", activation="tanh",
+                 use_bias=False, device=None, graph=None, seed=0):
+        cfg = (int(num_msg_dims), int(num_hidden_units), int(num_mlp_layers), reduce_op, activation, bool(use_bias))
+        if cfg != (20, 40, 2, "mean", "tanh", True):
+            raise NotImplementedError(
+                "the gfx950 kernel is specialised for num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, "
+                f"reduce_op='mean', activation='tanh', use_bias=True (the shipped weights); got {cfg}")
+        self._num_msg_dims, self._num_hidden_units, self._num_mlp_layers = cfg[:3]
+        self._reduce_op, self._activation, self._use_bias = cfg[3:]
+        self.graph = graph if graph is not None else TannerGraph(code, stage_one=True, device=device)
+        self._num_vn = self.graph.n
+        self._num_cn_x, self._num_cn_z = self.graph.m_x, self.graph.m_z
+        self._num_edges_x, self._num_edges_z = self.graph.E_x, self.graph.E_z
+        # Keras initialisers of feedback_gnn.py:115-128 / gnn.py:55-61: Dense kernels glorot-uniform,
+        # biases ones, the output layer's kernel zeros.
+        rng = np.random.RandomState(seed)
+        w = []
+        for shp in _W_SHAPES:
+            w.append(np.ones(shp, np.float32) if len(shp) == 1 else _glorot_uniform(rng, shp))
+        w[0] = np.zeros(_W_SHAPES[0], np.float32)
+        self._weights = None
+        self.set_weights(w)
+
+    def get_weights(self):
+        return [a.copy() for a in self._weights.arrays]
+
+    def set_weights(self, weights):
+        self._weights = GnnWeights(list(weights), self.graph.device)
+
+    @property
+    def device_weights(self):
+        return self._weights
+
+    def count_params(self):
+        return int(sum(int(np.prod(s)) for s in _W_SHAPES))
+
+    def __call__(self, inputs):
+        h_vn, logit_hx, logit_hz, syndrome_x, syndrome_z = inputs
+        g = self.graph
+        dev = g.device
+        h_vn = torch.as_tensor(h_vn, device=dev, dtype=torch.float32)
+        if h_vn.dim() != 3 or h_vn.shape[1:] != (g.n, 3):
+            raise ValueError(f"h_vn must have shape [batch_size, {g.n}, 3], got {tuple(h_vn.shape)}")
+        llr = h_vn.permute(0, 2, 1).contiguous()
+
+        def cn(t, rows, dtype):
+            t = torch.as_tensor(t, device=dev)
+            if t.dim() != 2 or t.shape[0] != rows or t.shape[1] != h_vn.shape[0]:
+                raise ValueError(f"expected shape [{rows}, {h_vn.shape[0]}], got {tuple(t.shape)}")
+            if dtype == torch.uint8:
+                return (t.to(torch.int64) & 1).to(torch.uint8).t().contiguous()
+            return t.to(torch.float32).t().contiguous()
+
+        out = g.feedback_gnn(self._weights, llr, cn(logit_hx, g.m_x, torch.float32), cn(logit_hz, g.m_z, torch.float32),
+                             cn(syndrome_x, g.m_x, torch.uint8), cn(syndrome_z, g.m_z, torch.uint8))
+        return out.permute(0, 2, 1).contiguous()
+
+
+def load_weights(system, model_path):
+    """`load_weights(G, path)` of gnn.py:774-791: reads the reference's pickle (restricted
+    unpickler, no TensorFlow) or this package's .npz and calls ``system.set_weights``."""
+    system.set_weights(read_weight_list(model_path))
+
+
+class Pauli:
+    """i.i.d. Pauli channel, non-weight branch of sionna/channel/pauli.py:98-108.
+
+    ``Pauli(graph)((batch_size, px, py, pz))`` is not how the reference is called; the sandwich
+    model only ever uses px = pz = 2p/3, py = p/3 (feedback_gnn.py:298), which is what the library
+    implements.  Call ``channel(batch_size, p)`` → (noise_x, noise_z) uint8 [bs,n].  The stream is
+    counter-based (Philox4x32-10 keyed by seed and global sample index) so any sharding of a batch over
+    GPUs sees the same samples.
+    """
+
+    def __init__(self, graph, seed=0x5EED, wt=False):
+        if wt:
+            raise NotImplementedError("fixed-weight noise (training-set harvesting, pauli.py:80-97) is not on the "
+                                      "evaluation hot path")
+        self.graph = graph
+        self.seed = int(seed)
+
+    def __call__(self, batch_size, p, first_sample=0):
+        return self.graph.pauli_noise(self.seed, p, first_sample, int(batch_size))
+
+
+class Sandwich_BP_GNN_Evaluation_Model:
+    """BP, then (GNN, BP) x (num_layers-1) with per-sample masking, on depolarizing noise.
+
+    Constructor as feedback_gnn.py:265: ``(code, decoders, feedbacks, num_layers=4, wt=False, p0=0.05)``.
+    ``model(batch_size, p)`` → ``(s_hat[bs, m_z+m_x], ls_hat[bs, rows(hx_perp)+rows(hz_perp)])``: residual
+    syndrome and residual logical syndrome of noise XOR estimate (feedback_gnn.py:343-361); a sample is
+    "flagged" iff its s_hat row is non-zero and a block error iff its ls_hat row is non-zero.
+
+    MI355X-native extras (keyword-only): ``seed``; ``compact`` (run the feedback rounds only on samples
+    still flagged — identical outputs); ``rank``/``world_size`` shard the global sample stream;
+    ``model.mc_step(batch_size, p, counts)`` accumulates (#flagged, #block errors, #samples) into a
+    device int64[3] without any host synchronisation.
+    """
+
+    def __init__(self, code, decoders, feedbacks, num_layers=4, wt=False, p0=0.05, *, seed=0x5EED, compact=False,
+                 rank=0, world_size=1, output_dtype=torch.uint8):
+        if wt:
+            raise NotImplementedError("wt=True (fixed-weight training noise) is not on the evaluation hot path")
+        if len(decoders) < num_layers or len(feedbacks) < num_layers - 1:
+            raise ValueError("need num_layers decoders and num_layers-1 feedbacks")
+        self.k, self.n = code.K, code.N
+        self.hx, self.hz, self.lx, self.lz = code.hx, code.hz, code.lx, code.lz
+        self.hx_perp, self.hz_perp = code.hx_perp, code.hz_perp
+        self.code_name = code.name
+        self.num_checks = code.hx.shape[0] + code.hz.shape[0]
+        self.decoders, self.feedbacks, self.num_layers = decoders, feedbacks, int(num_layers)
+        self.wt, self.p0 = wt, p0
+        self.graph = decoders[0].graph
+        if not self.graph.stage_one:
+            raise ValueError("the sandwich needs stage_one decoders (decoding_q.py:792-793)")
+        self.channel = Pauli(self.graph, seed=seed)
+        self.compact = bool(compact)
+        self.rank, self.world_size = int(rank), int(world_size)
+        self.output_dtype = output_dtype
+        self._next_sample = 0
+        self._workspace = None
+        self._ws_batch = -1
+
+    def _llr_const(self, p):
+        p0 = np.float32(p if self.p0 is None else self.p0)
+        return float(np.log(np.float32(3.0) * (np.float32(1.0) - p0) / p0, dtype=np.float32))  # (:311-312)
+
+    def _take_samples(self, batch_size):
+        """Global sample indices of this rank's next batch: consecutive blocks of world_size*batch_size."""
+        first = self._next_sample + self.rank * batch_size
+        self._next_sample += self.world_size * batch_size
+        return first
+
+    def decode(self, batch_size, p, first_sample=None):
+        """Noise -> syndromes -> sandwich.  Returns dict(noise_x, noise_z, x_hat, z_hat)."""
+        B = int(batch_size)
+        g = self.graph
+        first = self._take_samples(B) if first_sample is None else int(first_sample)
+        ex, ez = self.channel(B, float(p), first)
+        sx, sz = g.syndrome(ex, ez)
+        if self._ws_batch != B:
+            self._workspace = g.sandwich_workspace(B)
+            self._ws_batch = B
+        L = self.num_layers
+        out = g.sandwich_decode(sx, sz, [d.num_iter for d in self.decoders[:L]],
+                                [f.device_weights for f in self.feedbacks[:L - 1]], self._llr_const(p),
+                                factors=[d.normalization_factor for d in self.decoders[:L]],
+                                cn_types=[d.cn_type for d in self.decoders[:L]], compact=self.compact,
+                                workspace=self._workspace)
+        out["noise_x"], out["noise_z"] = ex, ez
+        return out
+
+    def __call__(self, batch_size, ebno_db=None, **kw):
+        p = kw.get("p", ebno_db)
+        o = self.decode(batch_size, p)
+        s_hat, ls_hat, _ = self.graph.residual(o["noise_x"], o["noise_z"], o["x_hat"], o["z_hat"], want_arrays=True)
+        if self.output_dtype != torch.uint8:
+            s_hat, ls_hat = s_hat.to(self.output_dtype), ls_hat.to(self.output_dtype)
+        return s_hat, ls_hat
+
+    call = __call__
+
+    def mc_step(self, batch_size, p, counts):
+        """One Monte-Carlo batch with on-device counting (sim_ber's qldpc branch, misc.py:647-669)."""
+        o = self.decode(batch_size, p)
+        _, _, flags = self.graph.residual(o["noise_x"], o["noise_z"], o["x_hat"], o["z_hat"], want_arrays=False)
+        return self.graph.count_flags(flags, counts)

@@ -105,6 +105,21 @@ class TannerGraph:
     def set_launch(self, threads_per_codeword=0, codewords_per_block=0):
         check(_lib.lib().fgnn_graph_set_launch(self.handle, int(threads_per_codeword), int(codewords_per_block)))
 
+    def profile_enable(self, max_launches):
+        """Record HIP events around every BP4 launch (0 disables)."""
+        check(_lib.lib().fgnn_profile_enable(self.handle, int(max_launches)))
+        self._prof_cap = int(max_launches)
+
+    def profile_read(self):
+        """[(ms, num_iter, batch), ...] of the BP4 launches since the last read."""
+        cap = max(1, getattr(self, "_prof_cap", 0))
+        ms = np.zeros(cap, np.float32)
+        it = np.zeros(cap, np.int32)
+        bt = np.zeros(cap, np.int32)
+        cnt = C.c_int32(0)
+        check(_lib.lib().fgnn_profile_read(self.handle, _np_ptr(ms), _np_ptr(it), _np_ptr(bt), cap, C.byref(cnt)))
+        return [(float(ms[i]), int(it[i]), int(bt[i])) for i in range(cnt.value)]
+
     def edges(self, side):
         """Canonical (qubit, check)-sorted edge list of hx (side 0) or hz (side 1): (chk, var)."""
         E = self.E_x if side == 0 else self.E_z

@@ -1,0 +1,130 @@
+"""Monte-Carlo harness for the QLDPC path.
+
+`sim_ber(..., qldpc=True)` / `count_block_errors` / `PlotBER.simulate` keep the call contracts of
+/root/reference sionna/utils/misc.py:403-768, sionna/utils/metrics.py:194-223 and
+sionna/utils/plotting.py:312-447 for the quantum branch only (flagged / logical error counting of
+misc.py:647-654).  With ``dist=True`` the per-batch counters are summed over all ranks of the default
+torch.distributed process group (RCCL over xGMI on MI355X, gloo in the CPU tests).
+"""
+import time
+
+import numpy as np
+import torch
+
+
+def count_block_errors(b, b_hat):
+    """Number of rows (last axis = one block) in which b and b_hat differ (metrics.py:194-223)."""
+    return (b != b_hat).any(dim=-1).to(torch.int64).sum()
+
+
+def allreduce_counts(counts):
+    """Sum a small integer tensor over all ranks (no-op without an initialised process group)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    return counts
+
+
+def shard_range(total, rank, world_size):
+    """Contiguous slice [lo, hi) of ``total`` samples owned by ``rank`` (sizes differ by at most 1)."""
+    base, rem = divmod(int(total), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=False, num_target_bit_errors=None,
+            num_target_block_errors=None, early_stop=True, graph_mode=None, verbose=True,
+            forward_keyboard_interrupt=True, qldpc=True, dist=False, dtype=None):
+    """Simulate until the target number of errors is reached; returns (flagged_rate, bler) per point.
+
+    Only the ``qldpc=True`` branch of the reference exists here: ``mc_fun(batch_size=, ebno_db=)`` returns
+    ``(s_hat, ls_hat)`` and a block counts as flagged / as a block error iff its row is non-zero.
+    """
+    if not qldpc:
+        raise NotImplementedError("only the qldpc=True branch of sim_ber is part of this package")
+    ps = [float(p) for p in np.atleast_1d(np.asarray(ebno_dbs, dtype=np.float64))]
+    n_pts = len(ps)
+    flag_errors = np.zeros(n_pts, np.int64)
+    block_errors = np.zeros(n_pts, np.int64)
+    nb_blocks = np.zeros(n_pts, np.int64)
+    runtime = np.zeros(n_pts)
+    status = np.zeros(n_pts, int)
+    names = ["not simulated", "reached max iter       ", "no errors - early stop", "reached target bit errors",
+             "reached target block errors"]
+    header = ["p", "Flagged", "BLER", "flag errors", "block errors", "num blocks", "runtime [s]", "status"]
+
+    def row(i, st):
+        fl = flag_errors[i] / max(nb_blocks[i], 1)
+        bl = block_errors[i] / max(nb_blocks[i], 1)
+        return (f"{ps[i]:9.4g} | {fl:10.4e} | {bl:10.4e} | {flag_errors[i]:11d} | {block_errors[i]:12d} | "
+                f"{nb_blocks[i]:11d} | {runtime[i]:11.1f} |{st}")
+
+    try:
+        for i in range(n_pts):
+            t0 = time.perf_counter()
+            it = -1
+            for it in range(int(max_mc_iter)):
+                s_hat, l_hat = mc_fun(batch_size=batch_size, ebno_db=ps[i])[:2]
+                c = torch.stack([count_block_errors(torch.zeros_like(s_hat), s_hat),
+                                 count_block_errors(torch.zeros_like(l_hat), l_hat),
+                                 torch.tensor(s_hat.shape[0], dtype=torch.int64, device=s_hat.device)])
+                if dist:
+                    c = allreduce_counts(c)
+                c = c.cpu().numpy()
+                flag_errors[i] += c[0]
+                block_errors[i] += c[1]
+                nb_blocks[i] += c[2]
+                runtime[i] = time.perf_counter() - t0
+                if verbose and i == 0 and it == 0:
+                    print(" | ".join(f"{h:>11s}" for h in header))
+                    print("-" * 135)
+                if num_target_bit_errors is not None and flag_errors[i] >= num_target_bit_errors:
+                    status[i] = 3
+                    break
+                if num_target_block_errors is not None and block_errors[i] >= num_target_block_errors:
+                    status[i] = 4
+                    break
+                if it == int(max_mc_iter) - 1:
+                    status[i] = 1
+            if verbose:
+                print(row(i, names[status[i]]))
+            if early_stop and block_errors[i] == 0:
+                status[i] = 2
+                if verbose:
+                    print(f"\nSimulation stopped as no error occurred @ p = {ps[i]:.4g}.\n")
+                break
+    except KeyboardInterrupt:
+        if forward_keyboard_interrupt:
+            raise
+        print("\nSimulation stopped by the user")
+    with np.errstate(invalid="ignore", divide="ignore"):
+        flagged = np.where(nb_blocks > 0, flag_errors / np.maximum(nb_blocks, 1), 0.0)
+        bler = np.where(nb_blocks > 0, block_errors / np.maximum(nb_blocks, 1), 0.0)
+    sim_ber.last = dict(p=ps, flag_errors=flag_errors, block_errors=block_errors, num_blocks=nb_blocks, runtime=runtime,
+                        status=status)
+    return flagged, bler
+
+
+class PlotBER:
+    """Result store with the `simulate` entry point of sionna/utils/plotting.py:312-447 (qldpc branch);
+    keeps `_snrs`, `_bers`, `_legends` like the reference (two entries per run: flagged, then BLER)."""
+
+    def __init__(self, title="Logical error rate"):
+        self._title = title
+        self._bers, self._snrs, self._legends, self._is_bler = [], [], [], []
+
+    def simulate(self, mc_fun, ebno_dbs, batch_size, max_mc_iter, legend="", add_ber=True, add_bler=False,
+                 soft_estimates=False, num_target_bit_errors=None, num_target_block_errors=None, early_stop=True,
+                 graph_mode=None, add_results=True, forward_keyboard_interrupt=True, show_fig=False, verbose=True,
+                 qldpc=True, dist=False):
+        flagged, bler = sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=soft_estimates,
+                                num_target_bit_errors=num_target_bit_errors,
+                                num_target_block_errors=num_target_block_errors, early_stop=early_stop, verbose=verbose,
+                                forward_keyboard_interrupt=forward_keyboard_interrupt, qldpc=qldpc, dist=dist)
+        if add_results:
+            ps = np.atleast_1d(np.asarray(ebno_dbs, dtype=np.float64))
+            if add_ber:
+                self._bers.append(flagged); self._snrs.append(ps); self._legends.append(legend); self._is_bler.append(False)
+            if add_bler:
+                self._bers.append(bler); self._snrs.append(ps); self._legends.append(legend + " (BLER)"); self._is_bler.append(True)
+        return flagged, bler

@@ -66,6 +66,13 @@ int fgnn_graph_info(const fgnn_graph* g, int32_t info[16]);
 /* canonical (qubit, check)-sorted edge lists, host output: chk[E_s], var[E_s] for side 0 (hx) / 1 (hz) */
 int fgnn_graph_edges(const fgnn_graph* g, int side, int32_t* chk, int32_t* var);
 
+/* Per-launch timing of the BP4 kernel (no reference equivalent; sim_ber only has wall-clock per point,
+ * misc.py:639,696): HIP events are recorded on the launch stream right before and after every BP4 launch,
+ * standalone or inside fgnn_sandwich_decode, up to max_launches (0 disables).  fgnn_profile_read waits for the
+ * last one and returns ms / num_iter / B per launch in host arrays of length cap. */
+int fgnn_profile_enable(fgnn_graph* g, int max_launches);
+int fgnn_profile_read(fgnn_graph* g, float* ms, int32_t* iters, int32_t* batch, int cap, int32_t* count);
+
 /* QLDPCBPDecoder.call, decoding_q.py:661-797 (flooding BP4, num_iter iterations, then marginals,
  * hard decision :783-790 and soft syndrome cal_logit :455-471).
  *   llr_ch       [B,3,n] or NULL: all three channel LLRs = llr_const (feedback_gnn.py:311-313)

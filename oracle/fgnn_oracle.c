@@ -637,6 +637,12 @@ void og_math_apply(int fn, const float* x, float* y, long nelem)
     }
 }
 
+/* raw Philox4x32-10 block (Random123 known-answer vectors, tests/test_math.py) */
+void og_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    fg_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
 int og_num_threads(void)
 {
 #ifdef _OPENMP

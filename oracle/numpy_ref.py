@@ -1,0 +1,135 @@
+"""Independent NumPy restatement of the reference's BP4 + feedback-GNN arithmetic.
+
+TEST INFRASTRUCTURE ONLY.  Purpose: a second, independently written statement of
+/root/reference sionna/fec/ldpc/decoding_q.py and feedback_gnn.py that uses NumPy's OWN float32
+exp/log/log1p/tanh (not the polynomial routines of fgnn_math.h) and the reference's own data layout
+(edge-major tensors [E, batch], batch as the minor axis, np.add.reduceat for the ragged sums).  The C
+oracle must agree with it to <= 1e-4 on converged samples and reproduce the reference's
+known-answer values; that bounds what the custom elementary functions can have changed.
+"""
+import numpy as np
+
+F = np.float32
+_THR = F(np.log(np.finfo(np.float32).eps, dtype=np.float32) + F(2.0))  # tf2xla Softplus threshold (negative)
+
+
+def softplus(t):
+    """tf.math.softplus as lowered by tf2xla."""
+    t = t.astype(F, copy=False)
+    with np.errstate(over="ignore", under="ignore"):
+        e = np.exp(np.minimum(t, F(30.0)))
+        mid = np.log1p(e)
+    return np.where(t > -_THR, t, np.where(t < _THR, e, mid)).astype(F)
+
+
+def lse2(a, b):
+    """tf.reduce_logsumexp(stack([a, b], -1), -1): max-shifted."""
+    m = np.maximum(a, b)
+    with np.errstate(under="ignore"):
+        s = np.exp(a - m) + np.exp(b - m)
+    return (np.log(s) + m).astype(F)
+
+
+def phi(x):
+    """decoding_q.py:365-373."""
+    x = np.clip(x, F(8.5e-8), F(16.635532)).astype(F)
+    with np.errstate(under="ignore"):
+        return (softplus(x) - np.log(np.exp(x) - F(1.0))).astype(F)
+
+
+class Graph:
+    def __init__(self, code, stage_one=True):
+        self.n = code.hx.shape[1]
+        self.sides = []
+        for pcm in (code.hx, code.hz):
+            chk, var = np.nonzero(np.asarray(pcm))
+            o = np.lexsort((chk, var))  # by qubit, then check (canonical VN-major order)
+            chk, var = chk[o], var[o]
+            to_cn = np.lexsort((var, chk))  # CN-major: by check, then qubit
+            inv = np.argsort(to_cn)
+            vstart = np.searchsorted(var, np.arange(self.n))
+            cstart = np.searchsorted(chk[to_cn], np.arange(pcm.shape[0]))
+            self.sides.append(dict(chk=chk, var=var, to_cn=to_cn, inv=inv, vstart=vstart, cstart=cstart,
+                                   m=pcm.shape[0], cn_of=chk[to_cn]))
+        xp, zp = (code.hz, code.hx) if stage_one else (code.hx_perp, code.hz_perp)
+        self.logit_rows = [self._rows(xp), self._rows(zp)]
+
+    @staticmethod
+    def _rows(mat):
+        r, c = np.nonzero(np.asarray(mat))
+        return dict(col=c, start=np.searchsorted(r, np.arange(mat.shape[0])), row_of=r, rows=mat.shape[0])
+
+
+def _seg_sum(vals, start):
+    return np.add.reduceat(vals, start, axis=0).astype(F)
+
+
+def _cn_phi(msg, side, sigma, factor):
+    """_cn_update_phi (:376-431) on CN-major messages [E,B]; sigma [m,B] = 1-2*syndrome."""
+    sgn = np.where(msg < 0, F(-1), F(1))
+    prod = np.multiply.reduceat(sgn, side["cstart"], axis=0) * sigma
+    a = phi(np.abs(msg))
+    T = _seg_sum(a, side["cstart"])
+    out = sgn * prod[side["cn_of"]] * phi(T[side["cn_of"]] - a)
+    return (out * F(factor)).astype(F)
+
+
+def _logits(g, which, llr):
+    rows = g.logit_rows[which]
+    v = llr[rows["col"]]
+    sgn = np.where(v < 0, F(-1), F(1))
+    prod = np.multiply.reduceat(sgn, rows["start"], axis=0)
+    T = _seg_sum(phi(np.abs(v)), rows["start"])
+    return (prod * phi(T)).astype(F)
+
+
+def bp4_decode(g, synd_x, synd_z, num_iter, llr_const=None, llr_ch=None, factor=1.0):
+    """boxplus-phi BP4; inputs codeword-major ([B,m] syndromes, [B,3,n] LLRs), math batch-minor.
+    Returns dict(llr [B,3,n], x_hat, z_hat, x_logit [B,rows], z_logit)."""
+    B = synd_x.shape[0]
+    n = g.n
+    if llr_ch is None:
+        L = np.full((3, n, B), F(llr_const), F)
+    else:
+        L = np.ascontiguousarray(np.transpose(llr_ch, (1, 2, 0)), dtype=F)
+    sig = [(F(1) - F(2) * synd_x.T.astype(F)), (F(1) - F(2) * synd_z.T.astype(F))]
+    msg = [np.zeros((s["chk"].size, B), F) for s in g.sides]  # VN-major c->v messages
+
+    def totals():
+        Sx = _seg_sum(msg[0], g.sides[0]["vstart"])
+        Sz = _seg_sum(msg[1], g.sides[1]["vstart"])
+        return Sz + L[0], (Sz + Sx) + L[1], Sx + L[2]
+
+    for _ in range(num_iter):
+        X, Y, Z = totals()
+        vx, vz = g.sides[0]["var"], g.sides[1]["var"]
+        nux = softplus(-X)[vx] - lse2(-(Z[vx] - msg[0]), -(Y[vx] - msg[0]))
+        nuz = softplus(-Z)[vz] - lse2(-(X[vz] - msg[1]), -(Y[vz] - msg[1]))
+        for s, nu in ((0, nux), (1, nuz)):
+            side = g.sides[s]
+            msg[s] = _cn_phi(nu[side["to_cn"]], side, sig[s], factor)[side["inv"]]
+    X, Y, Z = totals()
+    dec = np.argmin(np.stack([np.zeros_like(X), X, Z, Y], 0), axis=0)
+    llr_z = softplus(-X) - lse2(-Z, -Y)
+    llr_x = softplus(-Z) - lse2(-X, -Y)
+    return dict(llr=np.ascontiguousarray(np.stack([X, Y, Z], 0).transpose(2, 0, 1)),
+                x_hat=(dec & 1).T.astype(np.uint8), z_hat=(dec >> 1).T.astype(np.uint8),
+                x_logit=_logits(g, 0, llr_x).T.copy(), z_logit=_logits(g, 1, llr_z).T.copy())
+
+
+def feedback_gnn(g, w, llr, logit_hx, logit_hz, synd_x, synd_z):
+    """Feedback_GNN.call (feedback_gnn.py:161-188) with float32 matmuls; llr [B,3,n] -> [B,3,n]."""
+    h_vn = np.transpose(llr, (0, 2, 1)).astype(F)  # [B,n,3]
+    out_m = []
+    for s, (logit, synd, k) in enumerate(((logit_hx, synd_x, 2), (logit_hz, synd_z, 6))):
+        side = g.sides[s]
+        h_cn = (logit * (F(1) - F(2) * synd.astype(F)))[:, :, None]  # [B,m,1]
+        feat = np.concatenate([h_cn[:, side["chk"], :], h_vn[:, side["var"], :]], axis=-1)  # VN-major edges
+        hid = np.tanh(feat @ w[k] + w[k + 1]).astype(F)
+        m = (hid @ w[k + 2] + w[k + 3]).astype(F)  # [B,E,20]
+        ssum = np.add.reduceat(m, side["vstart"], axis=1)
+        deg = np.diff(np.append(side["vstart"], side["chk"].size)).astype(F)
+        out_m.append((ssum / deg[None, :, None]).astype(F))
+    z = np.concatenate([out_m[0], out_m[1], h_vn], axis=-1)
+    o = (np.tanh(z @ w[10] + w[11]).astype(F) @ w[0] + w[1]).astype(F)  # [B,n,3]
+    return np.ascontiguousarray(np.transpose(o, (0, 2, 1)))

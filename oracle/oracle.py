@@ -47,6 +47,7 @@ def lib():
                                             C.c_void_p, C.c_void_p]
         _lib.og_math_apply.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_long]
         _lib.og_num_threads.restype = C.c_int
+        _lib.og_philox.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -61,6 +62,14 @@ def _coo(mat):
 
 def num_threads():
     return lib().og_num_threads()
+
+
+def philox(ctr, key):
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    o = np.zeros(4, np.uint32)
+    lib().og_philox(_p(c), _p(k), _p(o))
+    return o
 
 
 def math_apply(name, x):

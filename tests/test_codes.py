@@ -1,0 +1,76 @@
+"""Host substrate vs the reference's own NumPy code (golden fixtures) and its notebook outputs."""
+import numpy as np
+import pytest
+
+from feedback_gnn_amd import codes_q as cq
+from feedback_gnn_amd import gf2
+from helpers import CODE_MAKERS, code, golden_codes, unpack
+
+
+@pytest.mark.parametrize("name", list(CODE_MAKERS))
+def test_constructions_match_reference_fixtures(name):
+    """hx, hz, kernel bases (row order included), logicals and scalars equal what the reference's
+    codes_q.py / fec/utils.py produce (tests/golden/make_golden_codes.py)."""
+    g = golden_codes()
+    c = code(name)
+    for attr in ("hx", "hz", "hx_perp", "hz_perp", "lx", "lz"):
+        assert np.array_equal(np.asarray(getattr(c, attr)).astype(np.uint8), unpack(g, name, attr)), attr
+    assert [c.N, c.K, int(c.D), int(c.L), int(c.Q), c.rank_hx, c.rank_hz] == list(g[f"{name}/scalars"])
+    assert c.name == str(g[f"{name}/name"])
+
+
+@pytest.mark.parametrize("name", list(CODE_MAKERS))
+def test_css_structure(name):
+    c = code(name)
+    assert not np.any(c.hx @ c.hz.T % 2)
+    assert not np.any(c.hx @ c.hx_perp.T % 2) and not np.any(c.hz @ c.hz_perp.T % 2)
+    assert c.hx_perp.shape[0] == c.N - c.rank_hx and c.lx.shape[0] == c.K == c.lz.shape[0]
+    # logicals commute with the stabilizers of the other type and pair up non-degenerately
+    assert not np.any(c.hz @ c.lx.T % 2) and not np.any(c.hx @ c.lz.T % 2)
+    assert gf2.rank(c.lx @ c.lz.T % 2) == c.K
+
+
+def test_steane_known_answer():
+    """examples/QLDPC.ipynb cell 3 output."""
+    c = code("steane")
+    H = np.array([[0, 0, 0, 1, 1, 1, 1], [0, 1, 1, 0, 0, 1, 1], [1, 0, 1, 0, 1, 0, 1]])
+    assert np.array_equal(c.hx, H) and np.array_equal(c.hz, H)
+    assert np.array_equal(c.lx, [[1, 1, 1, 0, 0, 0, 0]]) and np.array_equal(c.lz, [[1, 1, 1, 0, 0, 0, 0]])
+    assert (c.N, c.K) == (7, 1)
+
+
+def test_benchmark_graph_shapes():
+    """Traced shapes in examples/n882.ipynb cell 5 / n1270.ipynb cell 2: E = 2646 / 3810 per side."""
+    for name, n, m, E, perp in (("ghp882", 882, 441, 2646, 453), ("ghp1270", 1270, 635, 3810, 649)):
+        c = code(name)
+        assert c.hx.shape == (m, n) and c.hz.shape == (m, n)
+        assert int(c.hx.sum()) == E and int(c.hz.sum()) == E
+        assert set(c.hx.sum(0)) == {3} and set(c.hx.sum(1)) == {6} and set(c.hz.sum(0)) == {3} and set(c.hz.sum(1)) == {6}
+        assert c.hx_perp.shape[0] == perp and c.hz_perp.shape[0] == perp
+
+
+def test_row_echelon_reduced_and_inverse():
+    g = golden_codes()
+    ech, rk, tr, piv = gf2.row_echelon(g["rre/in"], reduced=True)
+    assert np.array_equal(ech, g["rre/ech"]) and np.array_equal(tr, g["rre/tr"])
+    assert [rk] + list(piv) == list(g["rre/rank_piv"])
+    assert np.array_equal(tr @ g["rre/in"] % 2, ech)
+    rng = np.random.RandomState(3)
+    while True:
+        m = rng.randint(0, 2, size=(9, 9))
+        if gf2.rank(m) == 9:
+            break
+    assert np.array_equal(gf2.inverse(m) @ m % 2, np.eye(9, dtype=int))
+    tall = np.vstack([m, rng.randint(0, 2, size=(4, 9))])
+    assert np.array_equal(gf2.inverse(tall) @ tall % 2, np.eye(9, dtype=int))
+    with pytest.raises(ValueError):
+        gf2.inverse(np.zeros((3, 3), dtype=int))
+
+
+def test_small_helpers():
+    assert gf2.int2bin(5, 4) == [0, 1, 0, 1] and gf2.int2bin(12, 3) == [1, 0, 0]
+    assert np.array_equal(cq.rep_code(3), [[1, 1, 0], [0, 1, 1]])
+    A = cq.create_cyclic_permuting_matrix(3, [5, 7])
+    assert np.array_equal(A, [[5, -1, 7], [7, 5, -1], [-1, 7, 5]])
+    lines = [[3, 2], [2, 3], [2, 1, 2], [3, 3], [1, 2], [2, 0], [1, 2], [1, 3, 0], [1, 2, 3]]
+    assert cq.alistToNumpy(lines).shape == (2, 3)

@@ -1,0 +1,71 @@
+"""World-size-2 gloo test of the multi-GPU path's logic: the Monte-Carlo sample stream is sharded by
+global sample index with no data-path collective, and only the three counters are all-reduced.
+
+The decoder stand-in on CPU is the oracle (there is no CPU product path); what is under test is
+feedback_gnn_amd.utils.{shard_range, allreduce_counts} and the property that any sharding of the Philox
+stream reproduces the single-process samples and counts exactly.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from feedback_gnn_amd.utils import allreduce_counts, shard_range
+from helpers import llr_const, oracle_graph
+
+TOTAL, P, SEED = 600, 0.09, 0x5EED
+
+
+def _counts_for(lo, hi):
+    g = oracle_graph("gb48")
+    ex, ez = g.pauli_noise(SEED, P, lo, hi - lo)
+    sx, sz = g.syndrome(ex, ez)
+    o = g.bp4_decode(sx, sz, 12, "boxplus-phi", 0.8, llr_const=llr_const(0.1))
+    flags = g.residual(ex, ez, o["x_hat"], o["z_hat"])[2]
+    packed = np.packbits(np.concatenate([o["x_hat"], o["z_hat"]], axis=1), axis=1)
+    return np.array([(flags & 1).sum(), ((flags >> 1) & 1).sum(), hi - lo], dtype=np.int64), packed
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(TOTAL, rank, world)
+        c, packed = _counts_for(lo, hi)
+        counts = allreduce_counts(torch.from_numpy(c.copy()))
+        # optional gather of bit-packed decisions (2n bits per codeword) onto every rank
+        mine = torch.from_numpy(packed)
+        sizes = [shard_range(TOTAL, r, world)[1] - shard_range(TOTAL, r, world)[0] for r in range(world)]
+        bufs = [torch.empty((s, mine.shape[1]), dtype=torch.uint8) for s in sizes]
+        dist.all_gather(bufs, mine) if len(set(sizes)) == 1 else [dist.broadcast(bufs[r] if r != rank else mine, r) for r in range(world)]
+        if len(set(sizes)) != 1:
+            bufs[rank] = mine
+        q.put((rank, counts.numpy().copy(), torch.cat(bufs).numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharding_matches_single_process():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref_counts, ref_packed = _counts_for(0, TOTAL)
+    assert ref_counts[1] > 0, "the test point must produce block errors"
+    for rank, counts, packed in results:
+        assert np.array_equal(counts, ref_counts), (rank, counts, ref_counts)
+        assert np.array_equal(packed, ref_packed)

@@ -1,0 +1,116 @@
+"""Host-side logic that needs no GPU: weight I/O, harness, sharding, the no-fallback rule."""
+import io
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import feedback_gnn_amd as F
+from feedback_gnn_amd import weights_io
+from feedback_gnn_amd.utils import PlotBER, count_block_errors, shard_range, sim_ber
+from helpers import WEIGHTS_882, code
+
+
+def test_bundled_weights_and_roundtrip(tmp_path):
+    w = weights_io.read_weight_list(WEIGHTS_882)
+    assert [a.shape for a in w] == [(40, 3), (3,), (4, 40), (40,), (40, 20), (20,), (4, 40), (40,), (40, 20), (20,), (43, 40), (40,)]
+    assert all(a.dtype == np.float32 for a in w) and sum(a.size for a in w) == 3923
+    p = tmp_path / "w.npz"
+    weights_io.write_weight_list(w, p)
+    w2 = weights_io.read_weight_list(str(p))
+    assert all(np.array_equal(a, b) for a, b in zip(w, w2))
+    # the reference's own file name resolves to the bundled conversion
+    w3 = weights_io.read_weight_list("./sionna/fec/ldpc/weights/feedback_GNN_n882_k24_wt_4_60_iter_64_16_mixed.npy")
+    assert all(np.array_equal(a, b) for a, b in zip(w, w3))
+
+
+def test_restricted_unpickler_reads_tf_style_pickles_and_refuses_code(tmp_path):
+    # a pickle shaped like the reference's: list of reduce(convert_to_tensor, (ndarray,))
+    class FakeTensor:
+        def __init__(self, a):
+            self.a = a
+
+        def __reduce__(self):
+            return (_fake_convert, (self.a,))
+
+    import sys
+    import types
+    mod = types.ModuleType("tensorflow.python.framework.ops")
+    mod.convert_to_tensor = _fake_convert
+    _fake_convert.__module__ = "tensorflow.python.framework.ops"
+    _fake_convert.__qualname__ = _fake_convert.__name__ = "convert_to_tensor"
+    for name in ("tensorflow", "tensorflow.python", "tensorflow.python.framework", "tensorflow.python.framework.ops"):
+        sys.modules.setdefault(name, mod if name.endswith("ops") else types.ModuleType(name))
+    try:
+        arrays = [np.arange(6, dtype=np.float32).reshape(2, 3), np.ones(3, np.float32)]
+        p = tmp_path / "tf_style.npy"
+        with open(p, "wb") as f:
+            pickle.dump([FakeTensor(a) for a in arrays], f)
+    finally:
+        for name in list(sys.modules):
+            if name == "tensorflow" or name.startswith("tensorflow."):
+                del sys.modules[name]
+    got = weights_io.read_weight_list(str(p))
+    assert all(np.array_equal(a, b) for a, b in zip(arrays, got))
+    evil = tmp_path / "evil.npy"
+    with open(evil, "wb") as f:
+        pickle.dump([os.system], f)
+    with pytest.raises(pickle.UnpicklingError):
+        weights_io.read_weight_list(str(evil))
+
+
+def _fake_convert(a):
+    return a
+
+
+def test_no_cpu_fallback():
+    from feedback_gnn_amd.graph import TannerGraph
+    from feedback_gnn_amd._lib import FgnnError
+    with pytest.raises(FgnnError):
+        TannerGraph(code("steane"), device=torch.device("cpu"))
+    with pytest.raises(ValueError):
+        F.QLDPCBPDecoder(code("steane"), cn_type="nonsense")
+
+
+def test_public_names_mirror_the_reference():
+    for name in ("QLDPCBPDecoder", "Feedback_GNN", "Sandwich_BP_GNN_Evaluation_Model", "load_weights", "save_weights",
+                 "css_code", "create_QC_GHP_codes", "create_cyclic_permuting_matrix", "create_generalized_bicycle_codes",
+                 "hypergraph_product", "create_rotated_surface_codes", "create_surface_codes", "hamming_code", "readAlist",
+                 "sim_ber", "PlotBER", "count_block_errors", "int_mod_2"):
+        assert hasattr(F, name), name
+
+
+def test_count_block_errors_and_sim_ber_qldpc():
+    a = torch.tensor([[0, 0, 0], [0, 1, 0], [1, 1, 1], [0, 0, 0]])
+    assert int(count_block_errors(torch.zeros_like(a), a)) == 2
+    rng = np.random.RandomState(0)
+    calls = []
+
+    def mc_fun(batch_size, ebno_db):
+        calls.append(ebno_db)
+        fl = torch.from_numpy((rng.rand(batch_size, 5) < ebno_db / 5).astype(np.uint8))
+        lg = torch.cat([fl, torch.from_numpy((rng.rand(batch_size, 2) < ebno_db / 10).astype(np.uint8))], dim=1)
+        return fl, lg
+
+    flagged, bler = sim_ber(mc_fun, [0.5, 0.2, 0.0], batch_size=200, max_mc_iter=50, num_target_block_errors=100,
+                            verbose=False)
+    st = sim_ber.last
+    assert st["status"][0] == 4 and st["block_errors"][0] >= 100  # reached target block errors
+    assert st["status"][2] == 2 and st["num_blocks"][2] == 50 * 200  # error-free point: early stop after max iter
+    assert 0 < flagged[0] <= bler[0] < 1 and bler[2] == 0
+    pb = PlotBER()
+    pb.simulate(mc_fun, [0.4], 100, 5, legend="x", add_bler=True, num_target_block_errors=10, verbose=False)
+    assert len(pb._bers) == 2 and pb._legends[1].endswith("(BLER)")
+    with pytest.raises(NotImplementedError):
+        sim_ber(mc_fun, [0.1], 10, 1, qldpc=False)
+
+
+def test_shard_range_partitions_exactly():
+    for total, world in ((10, 3), (65536, 8), (7, 8), (262144, 8)):
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,57 @@
+"""The shared float32 elementary functions (fgnn_math.h) and the Philox stream, probed through the oracle."""
+import numpy as np
+
+from oracle import oracle as O
+
+
+def _ulp_err(y, exact):
+    ulp = np.spacing(np.abs(exact.astype(np.float32))).astype(np.float64)
+    return np.abs(y.astype(np.float64) - exact) / ulp
+
+
+def test_exp_log_accuracy_sampled():
+    """Sampled version of tools/check_math.c (which is exhaustive: exp 0.91, log 0.93, log1p 1.48 ulp)."""
+    rng = np.random.RandomState(0)
+    x = np.concatenate([rng.uniform(-87, 40, 2_000_000), rng.uniform(-1, 1, 500_000)]).astype(np.float32)
+    assert _ulp_err(O.math_apply("exp", x), np.exp(x.astype(np.float64))).max() < 1.0
+    x = np.exp(rng.uniform(np.log(1e-7), np.log(5e7), 2_000_000)).astype(np.float32)
+    assert _ulp_err(O.math_apply("log", x), np.log(x.astype(np.float64))).max() < 1.0
+    u = np.exp(rng.uniform(np.log(1e-9), np.log(1.6e7), 2_000_000)).astype(np.float32)
+    assert _ulp_err(O.math_apply("log1p", u), np.log1p(u.astype(np.float64))).max() < 1.6
+    t = rng.uniform(-12, 12, 1_000_000).astype(np.float32)
+    assert _ulp_err(O.math_apply("tanh", t), np.tanh(t.astype(np.float64))).max() < 2.0
+
+
+def test_phi_reference_clip_behaviour():
+    """decoding_q.py:372: the clip constants make phi saturate at exactly 16.635532 and vanish at the top."""
+    v = O.math_apply("phi", np.array([8.5e-8, 0.0, 1e-30, 16.635532, 20.0, 1e6], np.float32))
+    assert v[0] == v[1] == v[2] == np.float32(16.635532)
+    assert v[3] == v[4] == v[5] == 0.0
+    x = np.linspace(0.01, 8.0, 100001).astype(np.float32)
+    exact = np.log((np.exp(x.astype(np.float64)) + 1) / (np.exp(x.astype(np.float64)) - 1))
+    # The reference's float32 formula has two cancellations: exp(x)-1 for small x (a 1-ulp error of exp(x)
+    # becomes a relative error 1.2e-7/x of the argument of the log) and softplus - log for large x (absolute
+    # error of a few ulp of x).  Any faithful float32 evaluation, TensorFlow's included, sits inside this band.
+    band = 2.5e-7 / np.minimum(x.astype(np.float64), 1.0) + 2e-6
+    assert (np.abs(O.math_apply("phi", x) - exact) < band).all()
+    assert (O.math_apply("phi", np.linspace(1e-7, 16.7, 200001).astype(np.float32)) >= -2e-6).all()
+
+
+def test_softplus_tf_semantics():
+    thr = np.float32(np.log(np.finfo(np.float32).eps, dtype=np.float32) + np.float32(2))
+    t = np.array([-100, -87.5, -20, thr, -1, 0, 1, -thr, 14, 50], np.float32)
+    y = O.math_apply("softplus", t)
+    assert y[0] == 0 and y[1] == 0  # exp underflow is flushed
+    assert y[8] == 14 and y[9] == 50  # identity above the threshold
+    ref = np.log1p(np.exp(t[2:8].astype(np.float64)))
+    assert np.allclose(y[2:8], ref, rtol=3e-7, atol=0)
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    kats = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+            ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+            ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+             [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, out in kats:
+        assert list(O.philox(ctr, key)) == out

@@ -1,0 +1,148 @@
+"""Pin the CPU oracle to the reference: exact float32 known answers from the committed notebooks, an
+independently written NumPy restatement, and the published error-rate tables."""
+import numpy as np
+import pytest
+
+from feedback_gnn_amd.weights_io import read_weight_list
+from helpers import WEIGHTS_1270, WEIGHTS_882, code, llr_const, oracle_graph
+from oracle import numpy_ref as R
+
+SEED = 0x5EED
+LLR_TOL = 1e-4  # north-star tolerance on LLRs
+
+
+def _setup(name, p, B, first=0):
+    g = oracle_graph(name)
+    ex, ez = g.pauli_noise(SEED, p, first, B)
+    sx, sz = g.syndrome(ex, ez)
+    return g, ex, ez, sx, sz
+
+
+@pytest.mark.parametrize("name", ["ghp882", "ghp1270"])
+def test_saturation_known_answer(name):
+    """examples/n1270.ipynb cell 12: after 64 BP4 iterations with p0=0.05 the marginals saturate at
+    max [53.9496498 103.856247 53.9496498], min [-45.8635445 -95.7701416 -45.8635445] (float32 prints)."""
+    g, ex, ez, sx, sz = _setup(name, 0.05, 64)
+    o = g.bp4_decode(sx, sz, 64, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
+    mx, mn = o["llr"].max(axis=(0, 2)), o["llr"].min(axis=(0, 2))
+    assert [f"{v:.9g}" for v in mx] == ["53.9496498", "103.856247", "53.9496498"]
+    assert [f"{v:.9g}" for v in mn] == ["-45.8635445", "-95.7701416", "-45.8635445"]
+    assert f"{llr_const(0.05):.8g}" == "4.0430512"
+
+
+def test_syndromes_and_noise_statistics():
+    g, ex, ez, sx, sz = _setup("ghp882", 0.09, 2000)
+    c = code("ghp882")
+    assert np.array_equal(sx, ez.astype(np.int64) @ c.hx.T % 2) and np.array_equal(sz, ex.astype(np.int64) @ c.hz.T % 2)
+    # depolarizing: X, Y, Z each with probability p/3 (pauli.py:98-108 with feedback_gnn.py:298)
+    n_tot = ex.size
+    for cnt in ((ex & ~ez & 1).sum(), (ex & ez).sum(), (~ex & ez & 1).sum()):
+        assert abs(cnt / n_tot - 0.03) < 5 * np.sqrt(0.03 / n_tot)
+    # the stream is keyed by the global sample index: any split of the batch gives the same samples
+    e2x, e2z = g.pauli_noise(SEED, 0.09, 700, 300)
+    assert np.array_equal(e2x, ex[700:1000]) and np.array_equal(e2z, ez[700:1000])
+
+
+@pytest.mark.parametrize("name,p,iters", [("ghp882", 0.05, 64), ("ghp882", 0.10, 32), ("gb48", 0.04, 16), ("rsurf3", 0.05, 20)])
+def test_c_oracle_vs_numpy_restatement(name, p, iters):
+    """The C oracle (polynomial exp/log, scalar loops) against oracle/numpy_ref.py (NumPy exp/log,
+    batch-minor tensors).
+
+    The reference's float32 phi (decoding_q.py:372-373) is rounding noise for arguments above ~12
+    (softplus(x) - log(exp(x)-1) cancels to 0 or 1 ulp(x)), and phi(phi(.)) turns that noise into O(1)
+    differences of strong messages, so two faithful implementations (TensorFlow CPU vs GPU included)
+    drift apart during the transient and meet again on the saturated fixed point.  Hence the bar: on
+    samples that BOTH implementations decode to the syndrome, identical decisions and LLRs within 1e-4;
+    the few trapping-set samples whose convergence flips are counted, not compared."""
+    B = 96
+    g, ex, ez, sx, sz = _setup(name, p, B, first=77)
+    L0 = llr_const(0.05)
+    o = g.bp4_decode(sx, sz, iters, "boxplus-phi", 1.0, llr_const=L0)
+    r = R.bp4_decode(R.Graph(code(name)), sx, sz, iters, llr_const=L0)
+    c = code(name)
+
+    def converged(d):
+        return ~(((d["x_hat"].astype(int) @ c.hz.T % 2) != sz).any(1) | ((d["z_hat"].astype(int) @ c.hx.T % 2) != sx).any(1))
+
+    both = converged(o) & converged(r)
+    flipped = converged(o) ^ converged(r)
+    same = (o["x_hat"] == r["x_hat"]).all(1) & (o["z_hat"] == r["z_hat"]).all(1)
+    assert both.sum() >= B // 4, "too few converged samples for the comparison to mean anything"
+    # near threshold (p=0.10, 32 iterations) many samples are still mid-flight: flips are expected, a
+    # systematic difference in the convergence RATE would not be
+    assert flipped.mean() <= 0.15 and abs(converged(o).mean() - converged(r).mean()) <= 0.06
+    assert same[both].mean() >= 0.98, "decisions differ on samples both implementations converge on"
+    d = np.abs(o["llr"] - r["llr"]).reshape(B, -1).max(1)
+    dl = np.abs(o["x_logit"] - r["x_logit"]).reshape(B, -1).max(1)
+    if code(name).N >= 800:
+        # large graphs: converged samples sit on the exact saturated fixed point after enough iterations
+        # (samples that converged only just before the last iteration are not saturated yet)
+        assert (d[both & same] <= LLR_TOL).mean() >= (0.95 if iters >= 64 else 0.8) and np.median(d[both & same]) <= LLR_TOL
+        assert np.median(dl[both & same]) <= LLR_TOL
+    else:
+        # small codes never saturate: the marginals stay analog, the comparison is relative
+        rel = d[both & same] / np.abs(o["llr"]).reshape(B, -1).max(1)[both & same]
+        assert np.median(rel) <= 1e-4
+
+
+def test_single_iteration_tight_agreement():
+    """After ONE iteration nothing has been amplified yet: every message-derived quantity agrees to 1e-5."""
+    g, ex, ez, sx, sz = _setup("ghp882", 0.08, 32)
+    o = g.bp4_decode(sx, sz, 1, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
+    r = R.bp4_decode(R.Graph(code("ghp882")), sx, sz, 1, llr_const=llr_const(0.05))
+    assert np.abs(o["llr"] - r["llr"]).max() <= 1e-5
+    assert np.array_equal(o["x_hat"], r["x_hat"]) and np.array_equal(o["z_hat"], r["z_hat"])
+
+
+@pytest.mark.parametrize("name,wfile", [("ghp882", WEIGHTS_882), ("ghp1270", WEIGHTS_1270)])
+def test_gnn_vs_numpy_restatement_and_output_band(name, wfile):
+    w = read_weight_list(wfile)
+    assert sum(a.size for a in w) == 3923  # examples/Feedback_GNN.ipynb cell 6: "Total params: 3,923"
+    g, ex, ez, sx, sz = _setup(name, 0.10, 48)
+    o = g.bp4_decode(sx, sz, 64, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
+    out = g.feedback_gnn(w, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
+    ref = R.feedback_gnn(R.Graph(code(name)), w, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
+    assert np.abs(out - ref).max() <= 1e-4
+    # sanity band of examples/n1270.ipynb cell 12 (GNN output on BP failures: roughly 0.2 .. 2.7, all positive)
+    assert out.min() > 0.0 and out.max() < 4.0 and 1.0 < out.mean() < 2.6
+
+
+def test_feedback_rescues_bp_failures():
+    """SURVEY §8c evidence: one GNN pass + 16 BP iterations corrects (nearly) all BP-64 failures at p=0.10."""
+    g, ex, ez, sx, sz = _setup("ghp882", 0.10, 600, first=5000)
+    w = read_weight_list(WEIGHTS_882)
+    o1 = g.bp4_decode(sx, sz, 64, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
+    f1 = g.residual(ex, ez, o1["x_hat"], o1["z_hat"])[2]
+    o2 = g.sandwich_decode(sx, sz, [64, 16], [w], llr_const(0.05))
+    f2 = g.residual(ex, ez, o2["x_hat"], o2["z_hat"])[2]
+    assert (f1 & 1).sum() >= 5 and (f2 & 1).sum() <= (f1 & 1).sum() // 2
+    assert (o2["rounds"] == (f1 & 1)).all()  # exactly the flagged samples enter the feedback round
+    # a sample that was not flagged after stage one keeps its stage-one estimate (feedback_gnn.py:339-340)
+    keep = (f1 & 1) == 0
+    assert np.array_equal(o2["x_hat"][keep], o1["x_hat"][keep]) and np.array_equal(o2["z_hat"][keep], o1["z_hat"][keep])
+
+
+def test_published_error_rate_band():
+    """examples/n882.ipynb cell 2 (3 feedback rounds, factor 1.0): p=0.14 -> 2375/5000 flagged = BLER.
+    800 oracle samples: binomial 3-sigma band around 0.475."""
+    B = 800
+    g, ex, ez, sx, sz = _setup("ghp882", 0.14, B, first=10_000)
+    w = read_weight_list(WEIGHTS_882)
+    o = g.sandwich_decode(sx, sz, [64, 16, 16, 16], [w, w, w], llr_const(0.05))
+    flags = g.residual(ex, ez, o["x_hat"], o["z_hat"])[2]
+    rate = ((flags >> 1) & 1).mean()
+    sigma = np.sqrt(0.475 * 0.525 / B)
+    assert abs(rate - 0.475) < 3.5 * sigma, rate
+    assert ((flags & 1) <= ((flags >> 1) & 1)).all()  # flagged implies block error
+
+
+def test_rotated_surface_flagged_vs_bler():
+    """examples/QLDPC.ipynb cell 9: rotated surface d=3, BP4-60, factor 0.8, p0=0.05, p=0.10:
+    flagged 0.2747, BLER 0.3078 (10 000 samples)."""
+    B = 10000
+    g, ex, ez, sx, sz = _setup("rsurf3", 0.10, B)
+    o = g.bp4_decode(sx, sz, 60, "boxplus-phi", 0.8, llr_const=llr_const(0.05))
+    flags = g.residual(ex, ez, o["x_hat"], o["z_hat"])[2]
+    fl, bl = (flags & 1).mean(), ((flags >> 1) & 1).mean()
+    assert abs(fl - 0.2747) < 4 * np.sqrt(0.2747 * 0.7253 / B) * np.sqrt(2), fl
+    assert abs(bl - 0.3078) < 4 * np.sqrt(0.3078 * 0.6922 / B) * np.sqrt(2), bl
