@@ -136,9 +136,37 @@ __device__ __forceinline__ float logit_row(const float* llr, const int* __restri
     return with_sign(fg_phi(T), neg);
 }
 
-template <int CN_TYPE>
+// c->v update of one (DC-regular) check with every message in registers: the phi rule of the benchmark
+// configurations without the LDS round trip of the runtime-degree version.  Same float ops, same order.
+template <int DC>
+__device__ __forceinline__ void cn_phi_regular(float* msg, const int (&sl)[DC], unsigned synd, float factor)
+{
+    float aa[DC];
+    unsigned ng[DC];
+    unsigned neg = synd;
+    float T = 0.0f;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        const float v = msg[sl[j]];
+        ng[j] = v < 0.0f;
+        neg ^= ng[j];
+        aa[j] = fg_phi(FG_ABS(v));
+        T = T + aa[j];
+    }
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        const float out = fg_phi(T - aa[j]);
+        msg[sl[j]] = with_sign(out, neg ^ ng[j]) * factor;
+    }
+}
+
+// DVX/DVZ/DC > 0: every qubit has exactly DVX hx-edges and DVZ hz-edges and every check DC edges, so a
+// qubit's slots are v*DVX+k / E_x+v*DVZ+k (no index loads) and a check's DC slots come as one packed
+// 16-byte row of g.cslot16.  DVX = 0: runtime degrees through the CSR tables.
+template <int CN_TYPE, int DVX, int DVZ, int DC>
 __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
 {
+    constexpr bool REGULAR = DVX > 0;
     extern __shared__ float lds[];
     const int cwl = threadIdx.x / a.tpc;
     const int lane = threadIdx.x - cwl * a.tpc;
@@ -165,36 +193,72 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
         // ---- variable nodes: _vn_update (:227-275) ----
         if (active)
             for (int v = lane; v < n; v += a.tpc) {
-                const int x0 = g.vptr_x[v], x1 = g.vptr_x[v + 1], z0 = g.vptr_z[v], z1 = g.vptr_z[v + 1];
-                float Sz = 0.0f, Sx = 0.0f;
-                for (int e = z0; e < z1; ++e) Sz = Sz + msg[e];
-                for (int e = x0; e < x1; ++e) Sx = Sx + msg[e];
                 const float lx = a.llr_ch ? Lch[v] : a.llr_const;
                 const float ly = a.llr_ch ? Lch[n + v] : a.llr_const;
                 const float lz = a.llr_ch ? Lch[2 * n + v] : a.llr_const;
-                const float Y = (Sz + Sx) + ly;
-                const float X = Sz + lx;
-                const float Z = Sx + lz;
-                const float numx = fg_softplus(-X);
-                const float numz = fg_softplus(-Z);
-                for (int e = x0; e < x1; ++e) {
-                    float m = msg[e];
-                    float Ze = Z - m, Ye = Y - m;
-                    msg[e] = numx - fg_lse2(-Ze, -Ye);
-                }
-                for (int e = z0; e < z1; ++e) {
-                    float m = msg[e];
-                    float Xe = X - m, Ye = Y - m;
-                    msg[e] = numz - fg_lse2(-Xe, -Ye);
+                if constexpr (REGULAR) {
+                    float* px = msg + v * DVX;
+                    float* pz = msg + g.E_x + v * DVZ;
+                    float mx[DVX], mz[DVZ];
+                    float Sz = 0.0f, Sx = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < DVZ; ++k) { mz[k] = pz[k]; Sz = Sz + mz[k]; }
+#pragma unroll
+                    for (int k = 0; k < DVX; ++k) { mx[k] = px[k]; Sx = Sx + mx[k]; }
+                    const float Y = (Sz + Sx) + ly;
+                    const float X = Sz + lx;
+                    const float Z = Sx + lz;
+                    const float numx = fg_softplus(-X);
+                    const float numz = fg_softplus(-Z);
+#pragma unroll
+                    for (int k = 0; k < DVX; ++k) {
+                        const float Ze = Z - mx[k], Ye = Y - mx[k];
+                        px[k] = numx - fg_lse2(-Ze, -Ye);
+                    }
+#pragma unroll
+                    for (int k = 0; k < DVZ; ++k) {
+                        const float Xe = X - mz[k], Ye = Y - mz[k];
+                        pz[k] = numz - fg_lse2(-Xe, -Ye);
+                    }
+                } else {
+                    const int x0 = g.vptr_x[v], x1 = g.vptr_x[v + 1], z0 = g.vptr_z[v], z1 = g.vptr_z[v + 1];
+                    float Sz = 0.0f, Sx = 0.0f;
+                    for (int e = z0; e < z1; ++e) Sz = Sz + msg[e];
+                    for (int e = x0; e < x1; ++e) Sx = Sx + msg[e];
+                    const float Y = (Sz + Sx) + ly;
+                    const float X = Sz + lx;
+                    const float Z = Sx + lz;
+                    const float numx = fg_softplus(-X);
+                    const float numz = fg_softplus(-Z);
+                    for (int e = x0; e < x1; ++e) {
+                        float m = msg[e];
+                        float Ze = Z - m, Ye = Y - m;
+                        msg[e] = numx - fg_lse2(-Ze, -Ye);
+                    }
+                    for (int e = z0; e < z1; ++e) {
+                        float m = msg[e];
+                        float Xe = X - m, Ye = Y - m;
+                        msg[e] = numz - fg_lse2(-Xe, -Ye);
+                    }
                 }
             }
         __syncthreads();
         // ---- check nodes of both graphs (:752-767) ----
         if (active)
             for (int c = lane; c < g.m; c += a.tpc) {
-                const int c0 = g.cptr[c], deg = g.cptr[c + 1] - c0;
                 const unsigned synd = (c < g.m_x ? sx[c] : sz[c - g.m_x]) & 1u;
-                cn_update<CN_TYPE>(msg, g.cslot + c0, deg, synd, a.factor);
+                if constexpr (REGULAR) {
+                    const uint4 pk = reinterpret_cast<const uint4*>(g.cslot16)[c];
+                    const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
+                    int sl[DC];
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) sl[j] = (int)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+                    if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI) cn_phi_regular<DC>(msg, sl, synd, a.factor);
+                    else cn_update<CN_TYPE>(msg, sl, DC, synd, a.factor);
+                } else {
+                    const int c0 = g.cptr[c], deg = g.cptr[c + 1] - c0;
+                    cn_update<CN_TYPE>(msg, g.cslot + c0, deg, synd, a.factor);
+                }
             }
         __syncthreads();
     }
@@ -258,16 +322,27 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
     }
 }
 
-template <int CN_TYPE>
-int launch_bp4(const fgnn_graph* g, const BpArgs& a, const LaunchGeom& L, size_t lds_bytes, hipStream_t st)
+template <int CN_TYPE, int DVX, int DVZ, int DC>
+int launch_bp4_k(const fgnn_graph* g, const BpArgs& a, const LaunchGeom& L, size_t lds_bytes, hipStream_t st)
 {
-    auto kern = bp4_kernel<CN_TYPE>;
+    auto kern = bp4_kernel<CN_TYPE, DVX, DVZ, DC>;
     if (lds_bytes > 48 * 1024)
         FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(L.blocks), dim3(L.threads), lds_bytes, st, g->d, a);
     FGNN_HIP_CHECK(hipGetLastError());
     return FGNN_OK;
+}
+
+template <int CN_TYPE>
+int launch_bp4(const fgnn_graph* g, const BpArgs& a, const LaunchGeom& L, size_t lds_bytes, hipStream_t st)
+{
+    const GraphDev& d = g->d;
+    if (d.cslot16 && !g->force_generic) {
+        if (d.dvx == 3 && d.dvz == 3 && d.dc == 6) return launch_bp4_k<CN_TYPE, 3, 3, 6>(g, a, L, lds_bytes, st);
+        if (d.dvx == 4 && d.dvz == 4 && d.dc == 8) return launch_bp4_k<CN_TYPE, 4, 4, 8>(g, a, L, lds_bytes, st);
+    }
+    return launch_bp4_k<CN_TYPE, 0, 0, 0>(g, a, L, lds_bytes, st);
 }
 
 }  // namespace

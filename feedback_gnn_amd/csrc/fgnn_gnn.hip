@@ -7,11 +7,16 @@
 // activation="tanh", use_bias=True (n882.py:45-51).
 //
 // The reference materialises [bs,E,4], [bs,E,40] and [bs,E,20] tensors in HBM (27 GB at
-// bs=65 536).  Here one thread owns one qubit: it walks the qubit's edges, runs the 4->40->20 edge
-// MLP in registers, averages, and runs the 43->40->3 node MLP; the only HBM traffic is the
-// [B,3,n] input/output and the two soft-syndrome vectors.  Weights are wave-uniform, so they
-// arrive through scalar loads (SGPR operands of v_fmac_f32), transposed at upload so that each
-// hidden unit's row is contiguous.
+// bs=65 536).  Here nothing but the [B,3,n] input/output and the two soft-syndrome vectors touches HBM.
+//
+// Two kernels:
+//  * gnn_mfma_kernel<DV> (degree-regular graphs, the benchmark codes): one wave owns 16 qubits at a time
+//    and runs every Dense layer as v_mfma_f32_16x16x4_f32 on TRANSPOSED problems (H^T = W^T F^T), so that
+//    the accumulator layout of one layer (column = qubit on the lane, rows in the 4 registers) is
+//    directly the B operand of the next layer — no LDS round trip, no cross-lane moves.  The weight
+//    matrices live in registers as A operands for the whole kernel; their rows are permuted at upload
+//    so that k-step s of the next layer finds hidden units 4s..4s+3 on lane groups 0..3.
+//  * gnn_kernel (any graph): one thread per qubit, weights by scalar loads, plain v_fma chains.
 //
 // Arithmetic order = oracle/fgnn_oracle.c (gnn_edge_side / gnn_one): every dot product is an fmaf
 // chain in ascending k starting from 0, then + bias; edge messages are summed in ascending check
@@ -80,6 +85,133 @@ __device__ __forceinline__ void side_mean(const GraphDev& g, const int* __restri
         const float fd = (float)deg;
 #pragma unroll
         for (int i = 0; i < MSG; ++i) mean[i] = mean[i] / fd;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA path.  v_mfma_f32_16x16x4_f32: A[16x4] (lane l holds A[l&15][l>>4]), B[4x16] (lane l holds
+// B[l>>4][l&15]), C/D[16x16] (lane l, register r holds D[4*(l>>4)+r][l&15]).  The result is a k-ordered
+// fmaf chain starting from C (cdna_hip_programming.md §3), i.e. exactly the oracle's dot product.
+//
+// Row permutation: output row rho = 4q'+r' of tile t carries unit 16t + 4r' + q'.  Then lane group q,
+// register r of tile t holds unit 4(4t+r) + q = "element q of k-step s = 4t+r" of the next layer.
+// Per-lane operand tables (built in fgnn_weights_create), entry e at lane_tab[e*64 + lane]:
+enum {
+    T_W1 = 0,    // + side*3 + t          A operand of layer 1 (K=4: g, X, Y, Z)
+    T_B1 = 6,    // + side*10 + s         bias of hidden unit 4s+q
+    T_W2 = 26,   // + (side*2+u)*10 + s   A operand of layer 2, output tile u, k-step s
+    T_B2 = 66,   // + side*5 + i          bias of message 4i+q (i<4) / 16+q (i=4)
+    T_WE = 76,   // + t*11 + s            A operand of vn_embed_mlp, k-step s (K = 43 -> 44)
+    T_BE = 109,  // + s
+    T_WO = 119,  // + s                   A operand of _llr_inv_embed (3 -> 16 rows)
+    T_BO = 129,  // + r                   bout[r] on lane group 0
+    T_COUNT = 132
+};
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+template <int DV>
+__global__ void __launch_bounds__(256, 2) gnn_mfma_kernel(GraphDev g, WeightsDev w, GnnArgs a)
+{
+    extern __shared__ float lds[];
+    const int slot_b = blockIdx.x;
+    const int b = a.index ? a.index[slot_b] : slot_b;
+    float* gcn = lds;  // [m_x] g_x then [m_z] g_z  (:168-172)
+    const int n = g.n;
+    for (int c = threadIdx.x; c < g.m_x; c += 256)
+        gcn[c] = a.logit_hx[(size_t)b * g.m_x + c] * ((a.synd_x[(size_t)b * g.m_x + c] & 1) ? -1.0f : 1.0f);
+    for (int c = threadIdx.x; c < g.m_z; c += 256)
+        gcn[g.m_x + c] = a.logit_hz[(size_t)b * g.m_z + c] * ((a.synd_z[(size_t)b * g.m_z + c] & 1) ? -1.0f : 1.0f);
+
+    const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = l & 15, q = l >> 4;
+    const float* tab = w.lane_tab + l;
+    // weights and biases: registers for the whole kernel
+    float w1[2][3], b1[2][10], w2[2][2][10], b2[2][5], we[3][11], be[10], wo[10], bo[3];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) w1[s2][t] = tab[(T_W1 + s2 * 3 + t) * 64];
+#pragma unroll
+        for (int s = 0; s < 10; ++s) b1[s2][s] = tab[(T_B1 + s2 * 10 + s) * 64];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s = 0; s < 10; ++s) w2[s2][u][s] = tab[(T_W2 + (s2 * 2 + u) * 10 + s) * 64];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) b2[s2][i] = tab[(T_B2 + s2 * 5 + i) * 64];
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int s = 0; s < 11; ++s) we[t][s] = tab[(T_WE + t * 11 + s) * 64];
+#pragma unroll
+    for (int s = 0; s < 10; ++s) {
+        be[s] = tab[(T_BE + s) * 64];
+        wo[s] = tab[(T_WO + s) * 64];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) bo[r] = tab[(T_BO + r) * 64];
+    __syncthreads();
+
+    const float* in = a.llr + (size_t)b * 3 * n;
+    float* out = a.out + (size_t)b * 3 * n;
+    const f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int ntiles = (n + 15) >> 4;
+    for (int tile = wave; tile < ntiles; tile += 4) {
+        const int vraw = tile * 16 + j;
+        const bool valid = vraw < n;
+        const int v = valid ? vraw : n - 1;
+        // lane group q feeds feature q of layer 1 (g, X, Y, Z) and element q of the last embed k-step (X, Y, Z, 0)
+        const float feat_own = (q == 0) ? 0.0f : in[(q - 1) * n + v];
+        const float xyz0 = (q < 3) ? in[q * n + v] : 0.0f;
+        float mean[2][5];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int ebase = (s2 ? g.E_x : 0) + v * DV;
+            const float* gside = gcn + (s2 ? g.m_x : 0);
+            float esum[5];
+#pragma unroll
+            for (int k = 0; k < DV; ++k) {
+                const float gv = gside[g.vchk[ebase + k]];
+                const float F = (q == 0) ? gv : feat_own;  // (:175-178)
+                f4 d[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) d[t] = mfma4(w1[s2][t], F, zero);
+                float H[10];
+#pragma unroll
+                for (int s = 0; s < 10; ++s) H[s] = fg_tanh(d[s >> 2][s & 3] + b1[s2][s]);
+                f4 m0 = zero, m1 = zero;
+#pragma unroll
+                for (int s = 0; s < 10; ++s) {
+                    m0 = mfma4(w2[s2][0][s], H[s], m0);
+                    m1 = mfma4(w2[s2][1][s], H[s], m1);
+                }
+                float msg[5] = {m0[0] + b2[s2][0], m0[1] + b2[s2][1], m0[2] + b2[s2][2], m0[3] + b2[s2][3], m1[0] + b2[s2][4]};
+#pragma unroll
+                for (int i = 0; i < 5; ++i) esum[i] = (k == 0) ? msg[i] : esum[i] + msg[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) mean[s2][i] = esum[i] / (float)DV;  // reduce_mean (:139-141)
+        }
+        // vn_embed_mlp on [m_x | m_z | X,Y,Z] then _llr_inv_embed  (:186)
+        f4 e[3] = {zero, zero, zero};
+#pragma unroll
+        for (int s = 0; s < 11; ++s) {
+            const float Bs = (s < 5) ? mean[0][s] : (s < 10) ? mean[1][s - 5] : xyz0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) e[t] = mfma4(we[t][s], Bs, e[t]);
+        }
+        f4 o = zero;
+#pragma unroll
+        for (int s = 0; s < 10; ++s) o = mfma4(wo[s], fg_tanh(e[s >> 2][s & 3] + be[s]), o);
+        if (valid && q == 0) {
+            out[v] = o[0] + bo[0];
+            out[n + v] = o[1] + bo[1];
+            out[2 * n + v] = o[2] + bo[2];
+        }
     }
 }
 
@@ -181,6 +313,43 @@ extern "C" int fgnn_weights_create(const float* const host_arrays[12], int devic
     off[11] = push(4);
     std::memcpy(&h[off[11]], host_arrays[1], 3 * sizeof(float));
 
+    // per-lane MFMA operand tables (see the T_* enum above)
+    const size_t off_tab = push((size_t)T_COUNT * 64);
+    {
+        float* T = &h[off_tab];
+        auto put = [&](int entry, int lane, float val) { T[(size_t)entry * 64 + lane] = val; };
+        for (int lane = 0; lane < 64; ++lane) {
+            const int rho = lane & 15, kk = lane >> 4, qp = rho >> 2, rp = rho & 3, qq = lane >> 4;
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float* W1 = host_arrays[2 + 4 * s2];
+                const float* B1 = host_arrays[3 + 4 * s2];
+                const float* W2 = host_arrays[4 + 4 * s2];
+                const float* B2 = host_arrays[5 + 4 * s2];
+                for (int t = 0; t < 3; ++t) {
+                    const int unit = 16 * t + 4 * rp + qp;
+                    put(T_W1 + s2 * 3 + t, lane, unit < HID ? W1[kk * HID + unit] : 0.0f);
+                }
+                for (int s = 0; s < 10; ++s) put(T_B1 + s2 * 10 + s, lane, B1[4 * s + qq]);
+                for (int u = 0; u < 2; ++u)
+                    for (int s = 0; s < 10; ++s) {
+                        const int mu = (u == 0) ? 4 * rp + qp : (rp == 0 ? 16 + qp : -1);
+                        put(T_W2 + (s2 * 2 + u) * 10 + s, lane, mu >= 0 ? W2[(4 * s + kk) * MSG + mu] : 0.0f);
+                    }
+                for (int i = 0; i < 5; ++i) put(T_B2 + s2 * 5 + i, lane, B2[i < 4 ? 4 * i + qq : 16 + qq]);
+            }
+            for (int t = 0; t < 3; ++t)
+                for (int s = 0; s < 11; ++s) {
+                    const int unit = 16 * t + 4 * rp + qp, k = 4 * s + kk;
+                    put(T_WE + t * 11 + s, lane, (unit < HID && k < 43) ? host_arrays[10][k * HID + unit] : 0.0f);
+                }
+            for (int s = 0; s < 10; ++s) {
+                put(T_BE + s, lane, host_arrays[11][4 * s + qq]);
+                put(T_WO + s, lane, rho < 3 ? host_arrays[0][(4 * s + kk) * 3 + rho] : 0.0f);
+            }
+            for (int r = 0; r < 3; ++r) put(T_BO + r, lane, host_arrays[1][r]);
+        }
+    }
+
     fgnn_weights* w = new fgnn_weights();
     w->device = device;
     w->blob = nullptr;
@@ -202,6 +371,7 @@ extern "C" int fgnn_weights_create(const float* const host_arrays[12], int devic
     w->d.be = base + off[9];
     w->d.wout = base + off[10];
     w->d.bout = base + off[11];
+    w->d.lane_tab = base + off_tab;
     *out = w;
     return FGNN_OK;
 }
@@ -237,6 +407,13 @@ int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const flo
     a.synd_z = synd_z;
     a.out = out;
     a.index = index;
+    if (g->d.dvx == 3 && g->d.dvz == 3 && !g->force_generic) {
+        // degree-regular graph: MFMA kernel, one codeword per 256-thread workgroup
+        hipLaunchKernelGGL(gnn_mfma_kernel<3>, dim3(B), dim3(256), (size_t)a.lds_per_cw * sizeof(float),
+                           static_cast<hipStream_t>(stream), g->d, w->d, a);
+        FGNN_HIP_CHECK(hipGetLastError());
+        return FGNN_OK;
+    }
     size_t lds_bytes = (size_t)a.lds_per_cw * sizeof(float) * (size_t)L.cpb;
     hipLaunchKernelGGL(gnn_kernel, dim3(L.blocks), dim3(L.threads), lds_bytes, static_cast<hipStream_t>(stream), g->d, w->d, a);
     FGNN_HIP_CHECK(hipGetLastError());

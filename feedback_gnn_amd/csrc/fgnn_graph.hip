@@ -62,10 +62,14 @@ void default_launch(fgnn_graph* g)
     // workgroup stays <= 512 threads where possible (several workgroups per CU hide each other's
     // barriers).  Small codes pack several codewords into one workgroup.
     const int nodes = std::max(g->d.n, g->d.m);
-    int npt = (nodes + 511) / 512;
-    int tpc = (nodes + npt - 1) / npt;
+    int tpc = nodes;
     int cpb = 1;
-    if (tpc >= 64) {
+    if (nodes >= 256) {
+        // 4 waves = one per SIMD; ~7 workgroups of [[882,24]] fit a CU's LDS and cover each other's barriers
+        // (measured on MI355X: 256 beats 448/512/1024 by 6-20 %; wave counts that are not a multiple of 4
+        // load the SIMDs unevenly)
+        tpc = 256;
+    } else if (tpc >= 64) {
         tpc = (tpc + 63) / 64 * 64;
     } else {
         int p2 = 1;
@@ -159,6 +163,15 @@ extern "C" int fgnn_graph_create(int n, int m_x, int m_z, int nnz_x, const int32
     d.dvz = uniform_degree(vptr[1]);
     d.dc = uniform_degree(cptr);
     int rc;
+    if (d.dvx > 0 && d.dvz > 0 && d.dc > 0 && d.dc <= 8 && d.E < 65536) {
+        std::vector<uint16_t> pk((size_t)d.m * 8, 0);
+        for (int c = 0; c < d.m; ++c)
+            for (int j = 0; j < d.dc; ++j) pk[(size_t)c * 8 + j] = (uint16_t)cslot[cptr[c] + j];
+        if ((rc = upload(g, pk, &d.cslot16))) {
+            fgnn_graph_destroy(g);
+            return rc;
+        }
+    }
     if ((rc = upload(g, vptr_x, &d.vptr_x)) || (rc = upload(g, vptr_z, &d.vptr_z)) || (rc = upload(g, vchk, &d.vchk)) ||
         (rc = upload(g, cptr, &d.cptr)) || (rc = upload(g, cslot, &d.cslot)) || (rc = upload(g, cvn, &d.cvn))) {
         fgnn_graph_destroy(g);
@@ -223,6 +236,14 @@ extern "C" int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, in
     g->tpc = tpc;
     g->cpb = cpb;
     g->user_launch = true;
+    return FGNN_OK;
+}
+
+// testing hook: force the runtime-degree kernel on regular graphs (both paths must give the same bits)
+extern "C" int fgnn_graph_force_generic(fgnn_graph* g, int on)
+{
+    if (!g) return fgnn_fail(FGNN_ERR_ARG, "graph is NULL");
+    g->force_generic = on != 0;
     return FGNN_OK;
 }
 

@@ -18,6 +18,7 @@ struct GraphDev {
     const int* cptr;    // [m+1] combined checks: hx rows 0..m_x-1 then hz rows; offsets into cslot/cvn
     const int* cslot;   // [E]   message slot of the k-th edge of a check (ascending qubit)
     const int* cvn;     // [E]   qubit of that edge
+    const uint16_t* cslot16;  // [m][8] packed slot rows for DC-regular graphs with DC <= 8 and E < 65536, else null
     // CSR row sets (fgnn_graph_set_rows)
     int rows[4];
     const int* rptr[4];
@@ -31,6 +32,7 @@ struct fgnn_graph {
     int device;
     int tpc, cpb;  // threads per codeword, codewords per block
     bool user_launch;
+    bool force_generic = false;  // testing: run the runtime-degree kernel even on a regular graph
     std::vector<void*> allocs;
     // host copies of the canonical edge lists (fgnn_graph_edges)
     std::vector<int32_t> h_chk[2], h_var[2];
@@ -52,6 +54,7 @@ struct WeightsDev {
     const float* be;      // [40]
     const float* wout;    // [40][4]  (3 padded to 4)
     const float* bout;    // [4]
+    const float* lane_tab;  // [132][64] per-lane MFMA operand / bias tables (fgnn_gnn.hip, mfma path)
 };
 
 struct fgnn_weights {

@@ -101,6 +101,14 @@ FG_FN float fg_log(float x)
     return fg_log_core(m - 1.0f, (float)e);
 }
 
+/* log(w) for w in [1, 2]: same bits as fg_log(w) (same reduced argument, same core), cheaper split. */
+FG_FN float fg_log_1to2(float w)
+{
+    int big = w >= 1.41421354f; /* bits 0x3fb504f3 = 2*sqrt(.5): fg_log switches exponent here too */
+    float m = big ? 0.5f * w : w;
+    return fg_log_core(m - 1.0f, big ? 1.0f : 0.0f);
+}
+
 /* log(1+u) for u in [0, 2^24].  The exponent e is read from RN(1+u); the reduced argument
  * f = (1+u)*2^-e - 1 is then formed by ONE fma from u itself, so no bits of u are lost. */
 FG_FN float fg_log1p(float u)
@@ -133,7 +141,7 @@ FG_FN float fg_lse2(float a, float b)
     float m = FG_MAX(a, b);
     float d = FG_ABS(a - b);
     float y = fg_exp(-FG_MIN(d, 20.0f));
-    return fg_log(1.0f + y) + m;
+    return fg_log_1to2(1.0f + y) + m;
 }
 
 /* QLDPCBPDecoder._phi, decoding_q.py:365-373:

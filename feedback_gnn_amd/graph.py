@@ -105,6 +105,10 @@ class TannerGraph:
     def set_launch(self, threads_per_codeword=0, codewords_per_block=0):
         check(_lib.lib().fgnn_graph_set_launch(self.handle, int(threads_per_codeword), int(codewords_per_block)))
 
+    def force_generic(self, on=True):
+        """Testing hook: run the runtime-degree kernel even on a degree-regular graph."""
+        check(_lib.lib().fgnn_graph_force_generic(self.handle, int(bool(on))))
+
     def profile_enable(self, max_launches):
         """Record HIP events around every BP4 launch (0 disables)."""
         check(_lib.lib().fgnn_profile_enable(self.handle, int(max_launches)))

@@ -60,6 +60,8 @@ int fgnn_graph_set_rows(fgnn_graph* g, int which, int rows, int nnz, const int32
 /* Launch geometry of the LDS-resident kernels: threads per codeword and codewords per workgroup.
  * 0 = keep the built-in heuristic.  (No reference equivalent: XLA picks its own launch shapes.) */
 int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords_per_block);
+/* Testing hook: on != 0 forces the runtime-degree (CSR) kernel even on a degree-regular graph. */
+int fgnn_graph_force_generic(fgnn_graph* g, int on);
 /* info[0..9] = n, m_x, m_z, E_x, E_z, threads_per_codeword, codewords_per_block, lds_bytes_per_block,
  *              regular(0/1), device */
 int fgnn_graph_info(const fgnn_graph* g, int32_t info[16]);

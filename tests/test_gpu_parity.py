@@ -147,3 +147,61 @@ def test_sandwich_and_residual_bit_exact(name, wfile, iters, p, compact):
     s1, l1, f1 = gg.residual(gx, gz, g["x_hat"], g["z_hat"])
     assert np.array_equal(s0, s1.cpu().numpy()) and np.array_equal(l0, l1.cpu().numpy())
     assert np.array_equal(f0, f1.cpu().numpy())
+
+
+@pytest.mark.parametrize("cn_type", ["boxplus-phi", "minsum", "boxplus"])
+def test_regular_and_runtime_degree_kernels_agree(cn_type):
+    """[[882,24]] is (3,3,6)-regular and takes the specialised kernel; forcing the CSR kernel must give the same bits."""
+    B = 40
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes("ghp882", 0.09, B, first=31)
+    gg = gpu_graph("ghp882")
+    assert gg.info()["regular"] == 1
+    o = oracle_graph("ghp882").bp4_decode(sx, sz, 20, cn_type, 0.8, llr_const=llr_const(0.05), return_msgs=True)
+    a = gg.bp4_decode(tx, tz, 20, cn_type, 0.8, llr_const=llr_const(0.05), return_msgs=True)
+    gg.force_generic(True)
+    try:
+        b = gg.bp4_decode(tx, tz, 20, cn_type, 0.8, llr_const=llr_const(0.05), return_msgs=True)
+    finally:
+        gg.force_generic(False)
+    _assert_bp_equal(o, a, "regular")
+    _assert_bp_equal(o, b, "generic")
+
+
+def test_launch_geometry_does_not_change_results():
+    B = 24
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes("ghp882", 0.09, B, first=99)
+    gg = gpu_graph("ghp882")
+    o = oracle_graph("ghp882").bp4_decode(sx, sz, 16, "boxplus-phi", 1.0, llr_const=llr_const(0.05), return_msgs=True)
+    try:
+        for tpc, cpb in ((256, 1), (128, 2), (512, 1), (1024, 1), (64, 4)):
+            gg.set_launch(tpc, cpb)
+            _assert_bp_equal(o, gg.bp4_decode(tx, tz, 16, "boxplus-phi", 1.0, llr_const=llr_const(0.05), return_msgs=True),
+                             f"tpc={tpc} cpb={cpb}")
+    finally:
+        gg.set_launch(0, 0)
+
+
+def test_gnn_mfma_and_valu_kernels_agree():
+    """The MFMA kernel (regular graphs) and the scalar-weight VALU kernel (any graph) both equal the oracle."""
+    from feedback_gnn_amd.graph import GnnWeights
+    from feedback_gnn_amd.weights_io import read_weight_list
+    name, B = "ghp882", 19
+    og, gg = oracle_graph(name), gpu_graph(name)
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, 0.11, B, first=4242)
+    w = read_weight_list(WEIGHTS_882)
+    # random weights too: the trained ones could hide a permutation error in a near-zero column
+    rng = np.random.RandomState(5)
+    wr = [rng.uniform(-0.7, 0.7, size=a.shape).astype(np.float32) for a in w]
+    o = og.bp4_decode(sx, sz, 32, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
+    for ww in (w, wr):
+        ref = og.feedback_gnn(ww, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
+        gw = GnnWeights(ww, gg.device)
+        args = (gw, to_gpu(o["llr"]), to_gpu(o["z_logit"]), to_gpu(o["x_logit"]), tx, tz)
+        a = gg.feedback_gnn(*args).cpu().numpy()
+        gg.force_generic(True)
+        try:
+            b = gg.feedback_gnn(*args).cpu().numpy()
+        finally:
+            gg.force_generic(False)
+        assert np.array_equal(ref, b), f"VALU kernel: max|d|={np.abs(ref - b).max()}"
+        assert np.array_equal(ref, a), f"MFMA kernel: max|d|={np.abs(ref - a).max()} first {np.argwhere(ref != a)[:4]}"
