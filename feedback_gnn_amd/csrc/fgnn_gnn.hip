@@ -113,49 +113,30 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 template <int DV>
-__global__ void __launch_bounds__(256, 2) gnn_mfma_kernel(GraphDev g, WeightsDev w, GnnArgs a)
+__global__ void __launch_bounds__(256, 4) gnn_mfma_kernel(GraphDev g, WeightsDev w, GnnArgs a)
 {
     extern __shared__ float lds[];
     const int slot_b = blockIdx.x;
     const int b = a.index ? a.index[slot_b] : slot_b;
-    float* gcn = lds;  // [m_x] g_x then [m_z] g_z  (:168-172)
+    // LDS: the per-lane operand tables [T_COUNT][64] (shared by the 4 waves; one conflict-free ds_read_b32 per
+    // MFMA keeps ~130 registers free, which buys 4 waves per SIMD instead of 2), then g_x | g_z  (:168-172)
+    float* tabs = lds;
+    float* gcn = lds + T_COUNT * 64;
     const int n = g.n;
+    for (int i = threadIdx.x; i < T_COUNT * 64; i += 256) tabs[i] = w.lane_tab[i];
     for (int c = threadIdx.x; c < g.m_x; c += 256)
         gcn[c] = a.logit_hx[(size_t)b * g.m_x + c] * ((a.synd_x[(size_t)b * g.m_x + c] & 1) ? -1.0f : 1.0f);
     for (int c = threadIdx.x; c < g.m_z; c += 256)
         gcn[g.m_x + c] = a.logit_hz[(size_t)b * g.m_z + c] * ((a.synd_z[(size_t)b * g.m_z + c] & 1) ? -1.0f : 1.0f);
+    __syncthreads();
 
     const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = l & 15, q = l >> 4;
-    const float* tab = w.lane_tab + l;
-    // weights and biases: registers for the whole kernel
-    float w1[2][3], b1[2][10], w2[2][2][10], b2[2][5], we[3][11], be[10], wo[10], bo[3];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t) w1[s2][t] = tab[(T_W1 + s2 * 3 + t) * 64];
-#pragma unroll
-        for (int s = 0; s < 10; ++s) b1[s2][s] = tab[(T_B1 + s2 * 10 + s) * 64];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int s = 0; s < 10; ++s) w2[s2][u][s] = tab[(T_W2 + (s2 * 2 + u) * 10 + s) * 64];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) b2[s2][i] = tab[(T_B2 + s2 * 5 + i) * 64];
-    }
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int s = 0; s < 11; ++s) we[t][s] = tab[(T_WE + t * 11 + s) * 64];
-#pragma unroll
-    for (int s = 0; s < 10; ++s) {
-        be[s] = tab[(T_BE + s) * 64];
-        wo[s] = tab[(T_WO + s) * 64];
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r) bo[r] = tab[(T_BO + r) * 64];
-    __syncthreads();
-
+#define TAB(e) tabs[toff + (e) * 64]
+    // the asm statements make the table OFFSET opaque per use site: hipcc would otherwise hoist all 132
+    // loop-invariant LDS reads back into registers and spill.  (Laundering the pointer instead would drop its
+    // LDS address space and turn every read into a flat_load.)
+#define FRESH_TAB() int toff = l; asm volatile("" : "+v"(toff))
     const float* in = a.llr + (size_t)b * 3 * n;
     float* out = a.out + (size_t)b * 3 * n;
     const f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -175,21 +156,23 @@ __global__ void __launch_bounds__(256, 2) gnn_mfma_kernel(GraphDev g, WeightsDev
             float esum[5];
 #pragma unroll
             for (int k = 0; k < DV; ++k) {
+                FRESH_TAB();
                 const float gv = gside[g.vchk[ebase + k]];
                 const float F = (q == 0) ? gv : feat_own;  // (:175-178)
                 f4 d[3];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) d[t] = mfma4(w1[s2][t], F, zero);
+                for (int t = 0; t < 3; ++t) d[t] = mfma4(TAB(T_W1 + s2 * 3 + t), F, zero);
                 float H[10];
 #pragma unroll
-                for (int s = 0; s < 10; ++s) H[s] = fg_tanh(d[s >> 2][s & 3] + b1[s2][s]);
+                for (int s = 0; s < 10; ++s) H[s] = fg_tanh(d[s >> 2][s & 3] + TAB(T_B1 + s2 * 10 + s));
                 f4 m0 = zero, m1 = zero;
 #pragma unroll
                 for (int s = 0; s < 10; ++s) {
-                    m0 = mfma4(w2[s2][0][s], H[s], m0);
-                    m1 = mfma4(w2[s2][1][s], H[s], m1);
+                    m0 = mfma4(TAB(T_W2 + (s2 * 2 + 0) * 10 + s), H[s], m0);
+                    m1 = mfma4(TAB(T_W2 + (s2 * 2 + 1) * 10 + s), H[s], m1);
                 }
-                float msg[5] = {m0[0] + b2[s2][0], m0[1] + b2[s2][1], m0[2] + b2[s2][2], m0[3] + b2[s2][3], m1[0] + b2[s2][4]};
+                float msg[5] = {m0[0] + TAB(T_B2 + s2 * 5 + 0), m0[1] + TAB(T_B2 + s2 * 5 + 1), m0[2] + TAB(T_B2 + s2 * 5 + 2),
+                                m0[3] + TAB(T_B2 + s2 * 5 + 3), m1[0] + TAB(T_B2 + s2 * 5 + 4)};
 #pragma unroll
                 for (int i = 0; i < 5; ++i) esum[i] = (k == 0) ? msg[i] : esum[i] + msg[i];
             }
@@ -197,22 +180,25 @@ __global__ void __launch_bounds__(256, 2) gnn_mfma_kernel(GraphDev g, WeightsDev
             for (int i = 0; i < 5; ++i) mean[s2][i] = esum[i] / (float)DV;  // reduce_mean (:139-141)
         }
         // vn_embed_mlp on [m_x | m_z | X,Y,Z] then _llr_inv_embed  (:186)
+        FRESH_TAB();
         f4 e[3] = {zero, zero, zero};
 #pragma unroll
         for (int s = 0; s < 11; ++s) {
             const float Bs = (s < 5) ? mean[0][s] : (s < 10) ? mean[1][s - 5] : xyz0;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) e[t] = mfma4(we[t][s], Bs, e[t]);
+            for (int t = 0; t < 3; ++t) e[t] = mfma4(TAB(T_WE + t * 11 + s), Bs, e[t]);
         }
         f4 o = zero;
 #pragma unroll
-        for (int s = 0; s < 10; ++s) o = mfma4(wo[s], fg_tanh(e[s >> 2][s & 3] + be[s]), o);
+        for (int s = 0; s < 10; ++s) o = mfma4(TAB(T_WO + s), fg_tanh(e[s >> 2][s & 3] + TAB(T_BE + s)), o);
         if (valid && q == 0) {
-            out[v] = o[0] + bo[0];
-            out[n + v] = o[1] + bo[1];
-            out[2 * n + v] = o[2] + bo[2];
+            out[v] = o[0] + TAB(T_BO + 0);
+            out[n + v] = o[1] + TAB(T_BO + 1);
+            out[2 * n + v] = o[2] + TAB(T_BO + 2);
         }
     }
+#undef TAB
+#undef FRESH_TAB
 }
 
 __global__ void __launch_bounds__(1024) gnn_kernel(GraphDev g, WeightsDev w, GnnArgs a)
@@ -409,7 +395,7 @@ int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const flo
     a.index = index;
     if (g->d.dvx == 3 && g->d.dvz == 3 && !g->force_generic) {
         // degree-regular graph: MFMA kernel, one codeword per 256-thread workgroup
-        hipLaunchKernelGGL(gnn_mfma_kernel<3>, dim3(B), dim3(256), (size_t)a.lds_per_cw * sizeof(float),
+        hipLaunchKernelGGL(gnn_mfma_kernel<3>, dim3(B), dim3(256), (size_t)(T_COUNT * 64 + a.lds_per_cw) * sizeof(float),
                            static_cast<hipStream_t>(stream), g->d, w->d, a);
         FGNN_HIP_CHECK(hipGetLastError());
         return FGNN_OK;

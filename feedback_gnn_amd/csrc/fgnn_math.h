@@ -7,7 +7,7 @@
  *   - by gcc    (-ffp-contract=off -mfma) into the CPU oracle (the .c files under oracle),
  * so a GPU result and an oracle result are the same bits, for every sample and every iteration.
  * Accuracy (tools/check_math.c, exhaustive over the domains used): exp <= 0.9 ulp,
- * log / log1p <= 1.0 ulp, tanh <= 2 ulp — the same class as TensorFlow's own Eigen / XLA kernels,
+ * log <= 0.93 ulp, log1p <= 1.5 ulp, tanh <= 2.7 ulp — the same class as TensorFlow's own Eigen / XLA kernels,
  * which are not correctly rounded either (SURVEY.md §8c "Third-party arithmetic").
  *
  * The composite functions restate TensorFlow op semantics used by the reference:
@@ -158,20 +158,24 @@ FG_FN float fg_phi(float x)
 /* ---- tanh / atanh (feedback-GNN activations, 'boxplus' check-node rule) ------------------ */
 FG_FN float fg_tanh(float x)
 {
-    float ax = FG_ABS(x);
-    /* small |x|: x + x^3*T4(x^2) */
-    float s = ax * ax;
-    float q = -6.274243351e-03f;
-    q = FG_FMA(q, s, 2.107168175e-02f);
-    q = FG_FMA(q, s, -5.385231227e-02f);
-    q = FG_FMA(q, s, 1.333258599e-01f);
-    q = FG_FMA(q, s, -3.333331645e-01f);
-    float lo = FG_FMA(ax * s, q, ax);
-    /* large |x|: 1 - 2/(e^{2|x|}+1) */
-    float y = fg_exp(FG_MIN(ax + ax, 40.0f));
-    float hi = 1.0f - 2.0f / (y + 1.0f);
-    float r = (ax < 0.55f) ? lo : hi;
-    return fg_u2f(fg_f2u(r) | (fg_f2u(x) & 0x80000000u));
+    /* tanh|x| = em1/(em1+2), em1 = expm1(2|x|) = 2^k*(e^r - 1) + (2^k - 1) with the reduction and the
+     * polynomial of fg_exp.  For k = 0 this is r + r^2*q(r) with r = 2|x| exactly, so small arguments keep
+     * full relative accuracy without a second branch. */
+    float t = FG_MIN(FG_ABS(x) + FG_ABS(x), 40.0f);
+    float tt = FG_FMA(t, FG_LOG2E, FG_RND_MAGIC);
+    float k = tt - FG_RND_MAGIC;
+    float r = FG_FMA(k, -FG_LN2_HI, t);
+    r = FG_FMA(k, -FG_LN2_LO, r);
+    float q = 1.381461043e-03f;
+    q = FG_FMA(q, r, 8.368710056e-03f);
+    q = FG_FMA(q, r, 4.166838899e-02f);
+    q = FG_FMA(q, r, 1.666652113e-01f);
+    q = FG_FMA(q, r, 4.999999404e-01f);
+    float pm1 = FG_FMA(r * r, q, r);                         /* e^r - 1 */
+    float sc = fg_u2f((fg_f2u(tt) << 23) + 0x3f800000u);     /* 2^k, k in [0, 58] */
+    float em1 = FG_FMA(sc, pm1, sc - 1.0f);
+    float y = em1 / (em1 + 2.0f);
+    return fg_u2f(fg_f2u(y) | (fg_f2u(x) & 0x80000000u));
 }
 
 /* atanh(x) = 0.5*log1p(2|x|/(1-|x|)), |x| <= 1-2^-23 */

