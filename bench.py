@@ -50,7 +50,8 @@ def main():
     ap.add_argument("--p", type=float, default=0.01)
     ap.add_argument("--code", default="ghp882", choices=["ghp882", "ghp1270"])
     ap.add_argument("--iters", default="64,16", help="BP iterations per stage")
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="codewords for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="codewords for the CPU baseline (0 = skip, -1 = sized from a probe to ~15 s of CPU work)")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
@@ -153,7 +154,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{code.name} sandwich BP4-{'+'.join(map(str, iters))} with {len(iters) - 1} feedback-GNN "
                                    f"pass(es), trained weights {wname}, boxplus-phi, factor 1.0, p0=0.05, depolarizing p={args.p}, "
-                                   f"noise+syndrome+decode+residual+count on device (BASELINE.json configs[2])",
+                                   f"noise+syndrome+decode+residual+count on device (BASELINE.json {'configs[2]' if args.code == 'ghp882' else 'configs[3] per-GPU shard'})",
                        "code": code.name, "batch_per_gpu": B, "global_batch": world * B, "bp_iters": iters, "p": args.p,
                        "parallelism": f"batch-sharded x{world}, no data-path collective",
                        "threads_per_codeword": info["threads_per_codeword"], "seed": SEED},
@@ -190,12 +191,22 @@ def main():
             t_c = timed(lambda: model_c.mc_step(B, args.p, cc))
             out["extras"] = {"bp4_only_cw_per_s (configs[1])": B / t_bp,
                              "sandwich_compacted_cw_per_s (feedback rounds only on flagged samples, same outputs)": B / t_c}
-        if args.cpu_sample > 0:
+        if args.cpu_sample != 0:
             from feedback_gnn_amd.weights_io import read_weight_list
             from oracle.oracle import OracleGraph, num_threads
-            S = args.cpu_sample
             og = OracleGraph(code)
             w = read_weight_list(wname)
+            S = args.cpu_sample
+            if S < 0:  # probe: 2 codewords per thread, then size the sample for ~15 s
+                probe = 2 * num_threads()
+                ex, ez = og.pauli_noise(SEED, args.p, 0, probe)
+                sx, sz = og.syndrome(ex, ez)
+                og.sandwich_decode(sx, sz, iters, [w] * (len(iters) - 1), L0)  # also warms the thread pool
+                t = time.perf_counter()
+                og.sandwich_decode(sx, sz, iters, [w] * (len(iters) - 1), L0)
+                rate = probe / (time.perf_counter() - t)
+                S = int(min(32768, max(512, 15.0 * rate)))
+                S -= S % 64
             ex, ez = og.pauli_noise(SEED, args.p, 0, S)
             sx, sz = og.syndrome(ex, ez)
             og.sandwich_decode(sx[:8], sz[:8], iters, [w] * (len(iters) - 1), L0)  # warm the thread pool
