@@ -37,6 +37,7 @@ _SIGNATURES = {
     "fgnn_graph_destroy": (None, [C.c_void_p]),
     "fgnn_graph_set_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "fgnn_graph_set_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "fgnn_graph_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "fgnn_graph_force_generic": (C.c_int, [C.c_void_p, C.c_int]),
     "fgnn_graph_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fgnn_graph_edges": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -39,6 +39,7 @@ struct BpArgs {
     float* msg_out_x;
     float* msg_out_z;
     const int* index;         // optional: workgroup slot -> sample (compacted rounds of the sandwich driver)
+    int shortcut;             // 1: wave-uniform exact shortcuts for saturated nodes (regular kernel)
 };
 
 __device__ __forceinline__ unsigned sign_bit(float x) { return fg_f2u(x) >> 31; }
@@ -139,18 +140,32 @@ __device__ __forceinline__ float logit_row(const float* llr, const int* __restri
 // c->v update of one (DC-regular) check with every message in registers: the phi rule of the benchmark
 // configurations without the LDS round trip of the runtime-degree version.  Same float ops, same order.
 template <int DC>
-__device__ __forceinline__ void cn_phi_regular(float* msg, const int (&sl)[DC], unsigned synd, float factor)
+__device__ __forceinline__ void cn_phi_regular(float* msg, const int (&sl)[DC], unsigned synd, float factor, float phi0,
+                                               bool shortcut)
 {
-    float aa[DC];
+    float v[DC], aa[DC];
     unsigned ng[DC];
     unsigned neg = synd;
+    bool sat = true;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        v[j] = msg[sl[j]];
+        ng[j] = v[j] < 0.0f;
+        neg ^= ng[j];
+        sat = sat && (FG_ABS(v[j]) >= FG_PHI_MAX);
+    }
+    // Saturation shortcut (exact): if every incoming |nu| >= 16.635532 then every phi(|nu|) is phi(clip max) = 0
+    // bit for bit, T = 0, and every outgoing magnitude is phi(0 - 0) = phi(clip min) =: phi0.  Taken only when ALL
+    // lanes of the wave are saturated (one v_cmp + s_cbranch), which is the steady state of a converged codeword.
+    if (shortcut && __all(sat)) {
+#pragma unroll
+        for (int j = 0; j < DC; ++j) msg[sl[j]] = with_sign(phi0, neg ^ ng[j]) * factor;
+        return;
+    }
     float T = 0.0f;
 #pragma unroll
     for (int j = 0; j < DC; ++j) {
-        const float v = msg[sl[j]];
-        ng[j] = v < 0.0f;
-        neg ^= ng[j];
-        aa[j] = fg_phi(FG_ABS(v));
+        aa[j] = fg_phi(FG_ABS(v[j]));
         T = T + aa[j];
     }
 #pragma unroll
@@ -158,6 +173,13 @@ __device__ __forceinline__ void cn_phi_regular(float* msg, const int (&sl)[DC], 
         const float out = fg_phi(T - aa[j]);
         msg[sl[j]] = with_sign(out, neg ^ ng[j]) * factor;
     }
+}
+
+// tf2xla softplus for |t| > 13.94 only: identity above, exp(t) below (flushed under -87); same bits as fg_softplus there.
+__device__ __forceinline__ float softplus_saturated(float t)
+{
+    const float y = fg_exp(FG_MIN(FG_MAX(t, -87.0f), 0.0f));
+    return (t > 0.0f) ? t : ((t < -87.0f) ? 0.0f : y);
 }
 
 // DVX/DVZ/DC > 0: every qubit has exactly DVX hx-edges and DVZ hz-edges and every check DC edges, so a
@@ -189,6 +211,8 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
     const uint8_t* sx = a.synd_x + (size_t)b * g.m_x;
     const uint8_t* sz = a.synd_z + (size_t)b * g.m_z;
 
+    const float phi0 = fg_phi(0.0f);  // = phi(clip min) = 16.6355324, the saturated message magnitude
+    (void)phi0;
     for (int it = 0; it < a.num_iter; ++it) {
         // ---- variable nodes: _vn_update (:227-275) ----
         if (active)
@@ -208,6 +232,28 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
                     const float Y = (Sz + Sx) + ly;
                     const float X = Sz + lx;
                     const float Z = Sx + lz;
+                    // Saturation shortcut (exact): |X|,|Z| beyond the softplus thresholds and every pair (Z_e,Y_e) /
+                    // (X_e,Y_e) at least 20 apart => log(1+exp(-d)) is log(1) = 0 bit for bit and lse2 returns its max.
+                    bool sat = a.shortcut && FG_ABS(X) > FG_SOFTPLUS_THRESH && FG_ABS(Z) > FG_SOFTPLUS_THRESH;
+#pragma unroll
+                    for (int k = 0; k < DVX; ++k) sat = sat && (FG_ABS((Z - mx[k]) - (Y - mx[k])) >= 20.0f);
+#pragma unroll
+                    for (int k = 0; k < DVZ; ++k) sat = sat && (FG_ABS((X - mz[k]) - (Y - mz[k])) >= 20.0f);
+                    if (a.shortcut && __all(sat)) {
+                        const float numx = softplus_saturated(-X);
+                        const float numz = softplus_saturated(-Z);
+#pragma unroll
+                        for (int k = 0; k < DVX; ++k) {
+                            const float Ze = Z - mx[k], Ye = Y - mx[k];
+                            px[k] = numx - (0.0f + FG_MAX(-Ze, -Ye));
+                        }
+#pragma unroll
+                        for (int k = 0; k < DVZ; ++k) {
+                            const float Xe = X - mz[k], Ye = Y - mz[k];
+                            pz[k] = numz - (0.0f + FG_MAX(-Xe, -Ye));
+                        }
+                        continue;
+                    }
                     const float numx = fg_softplus(-X);
                     const float numz = fg_softplus(-Z);
 #pragma unroll
@@ -253,7 +299,7 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
                     int sl[DC];
 #pragma unroll
                     for (int j = 0; j < DC; ++j) sl[j] = (int)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
-                    if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI) cn_phi_regular<DC>(msg, sl, synd, a.factor);
+                    if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI) cn_phi_regular<DC>(msg, sl, synd, a.factor, phi0, a.shortcut != 0);
                     else cn_update<CN_TYPE>(msg, sl, DC, synd, a.factor);
                 } else {
                     const int c0 = g.cptr[c], deg = g.cptr[c + 1] - c0;
@@ -381,6 +427,7 @@ int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float n
     a.msg_out_x = msg_out_x;
     a.msg_out_z = msg_out_z;
     a.index = index;
+    a.shortcut = g->shortcut ? 1 : 0;
     // floats per codeword: messages (>= 2n so the epilogue's binary LLRs fit) + channel LLRs
     a.lch_off = g->d.E > 2 * g->d.n ? g->d.E : 2 * g->d.n;
     int per_cw = a.lch_off + (llr_ch ? 3 * g->d.n : 0);

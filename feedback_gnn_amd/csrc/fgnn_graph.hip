@@ -239,6 +239,15 @@ extern "C" int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, in
     return FGNN_OK;
 }
 
+extern "C" int fgnn_graph_set_option(fgnn_graph* g, int option, int value)
+{
+    if (!g) return fgnn_fail(FGNN_ERR_ARG, "graph is NULL");
+    switch (option) {
+    case FGNN_OPT_SATURATION_SHORTCUT: g->shortcut = value != 0; return FGNN_OK;
+    default: return fgnn_fail(FGNN_ERR_ARG, "unknown option");
+    }
+}
+
 // testing hook: force the runtime-degree kernel on regular graphs (both paths must give the same bits)
 extern "C" int fgnn_graph_force_generic(fgnn_graph* g, int on)
 {

@@ -105,6 +105,10 @@ class TannerGraph:
     def set_launch(self, threads_per_codeword=0, codewords_per_block=0):
         check(_lib.lib().fgnn_graph_set_launch(self.handle, int(threads_per_codeword), int(codewords_per_block)))
 
+    def set_saturation_shortcut(self, on=True):
+        """Exact wave-uniform shortcut for saturated nodes in the regular BP4 kernel (default on; same results)."""
+        check(_lib.lib().fgnn_graph_set_option(self.handle, 1, int(bool(on))))
+
     def force_generic(self, on=True):
         """Testing hook: run the runtime-degree kernel even on a degree-regular graph."""
         check(_lib.lib().fgnn_graph_force_generic(self.handle, int(bool(on))))

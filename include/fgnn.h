@@ -60,6 +60,13 @@ int fgnn_graph_set_rows(fgnn_graph* g, int which, int rows, int nnz, const int32
 /* Launch geometry of the LDS-resident kernels: threads per codeword and codewords per workgroup.
  * 0 = keep the built-in heuristic.  (No reference equivalent: XLA picks its own launch shapes.) */
 int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords_per_block);
+/* Options.  FGNN_OPT_SATURATION_SHORTCUT (default 1): the degree-regular BP4 kernel skips the exp/log evaluation
+ * of a wave whose 64 nodes are all saturated (|v->c| >= 16.635532 at a check; totals beyond the softplus threshold
+ * and 20 apart at a qubit), writing the values those evaluations produce bit for bit (phi(clip max) = 0,
+ * phi(clip min), log(1) = 0).  Results are identical with 0 and 1; 0 evaluates every transcendental like the
+ * reference's fixed dataflow (decoding_q.py:732-767) and is what bench.py's headline number uses. */
+enum { FGNN_OPT_SATURATION_SHORTCUT = 1 };
+int fgnn_graph_set_option(fgnn_graph* g, int option, int value);
 /* Testing hook: on != 0 forces the runtime-degree (CSR) kernel even on a degree-regular graph. */
 int fgnn_graph_force_generic(fgnn_graph* g, int on);
 /* info[0..9] = n, m_x, m_z, E_x, E_z, threads_per_codeword, codewords_per_block, lds_bytes_per_block,

@@ -205,3 +205,28 @@ def test_gnn_mfma_and_valu_kernels_agree():
             gg.force_generic(False)
         assert np.array_equal(ref, b), f"VALU kernel: max|d|={np.abs(ref - b).max()}"
         assert np.array_equal(ref, a), f"MFMA kernel: max|d|={np.abs(ref - a).max()} first {np.argwhere(ref != a)[:4]}"
+
+
+@pytest.mark.parametrize("name,p", [("ghp882", 0.01), ("ghp882", 0.06), ("ghp1270", 0.02)])
+def test_saturation_shortcut_is_exact(name, p):
+    """Low p: codewords converge early and the wave-uniform shortcut fires for most of the 64 iterations.
+    With the option on and off the kernel must reproduce the oracle bit for bit."""
+    B = 64
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, p, B, first=777)
+    gg = gpu_graph(name)
+    o = oracle_graph(name).bp4_decode(sx, sz, 64, "boxplus-phi", 1.0, llr_const=llr_const(0.05), return_msgs=True)
+    assert np.abs(o["msg_x"]).max() == np.float32(16.635532)  # saturated state reached
+    try:
+        for on in (True, False):
+            gg.set_saturation_shortcut(on)
+            g = gg.bp4_decode(tx, tz, 64, "boxplus-phi", 1.0, llr_const=llr_const(0.05), return_msgs=True)
+            _assert_bp_equal(o, g, f"shortcut={on}")
+        # per-qubit channel LLRs (second-stage style input) and a normalisation factor != 1
+        llr = np.random.RandomState(3).uniform(0.3, 3.0, size=(B, 3, gg.n)).astype(np.float32)
+        o2 = oracle_graph(name).bp4_decode(sx, sz, 40, "boxplus-phi", 0.8, llr_ch=llr, return_msgs=True)
+        for on in (True, False):
+            gg.set_saturation_shortcut(on)
+            _assert_bp_equal(o2, gg.bp4_decode(tx, tz, 40, "boxplus-phi", 0.8, llr_ch=to_gpu(llr), return_msgs=True),
+                             f"llr_ch shortcut={on}")
+    finally:
+        gg.set_saturation_shortcut(True)

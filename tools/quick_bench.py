@@ -36,3 +36,10 @@ for tpc in (256, 448, 512):
     print(f"GNN tpc={tpc}: {dt*1e3:.1f} ms  {B/dt/1e3:.1f} k cw/s")
     dt = timeit(lambda: g.bp4_decode(sx, sz, 16, "boxplus-phi", 1.0, llr_ch=o['llr']))
     print(f"BP16 with llr_ch tpc={tpc}: {dt*1e3:.1f} ms")
+g.set_launch(0, 0)
+for p in (0.01, 0.05, 0.10):
+    ex, ez = g.pauli_noise(0x5EED, p, 0, B); sx, sz = g.syndrome(ex, ez)
+    for on in (False, True):
+        g.set_saturation_shortcut(on)
+        dt = timeit(lambda: g.bp4_decode(sx, sz, 64, "boxplus-phi", 1.0, llr_const=L0))
+        print(f"BP64 p={p} shortcut={on}: {dt*1e3:.1f} ms  {B/dt/1e3:.1f} k cw/s")
