@@ -1,0 +1,142 @@
+"""GPU tests of the reference-named Python classes (call contracts, shapes, dtypes, error behaviour) and the
+published statistical known answers reproduced through them."""
+import numpy as np
+import pytest
+import torch
+
+import feedback_gnn_amd as F
+from helpers import WEIGHTS_882, code, llr_const, oracle_graph
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EED
+
+
+def _syndromes(name, p, B, first=0):
+    og = oracle_graph(name)
+    ex, ez = og.pauli_noise(SEED, p, first, B)
+    sx, sz = og.syndrome(ex, ez)
+    return og, ex, ez, sx, sz
+
+
+def test_qldpcbpdecoder_stage_one_contract():
+    """decoder((llr_ch[bs,3,n], syndrome_x[m_x,bs], syndrome_z[m_z,bs])) -> 7-tuple (decoding_q.py:792-793)."""
+    c = code("ghp882")
+    B = 20
+    og, ex, ez, sx, sz = _syndromes("ghp882", 0.08, B)
+    dec = F.QLDPCBPDecoder(code=c, num_iter=32, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True)
+    llr = torch.full((B, 3, c.N), llr_const(0.05), dtype=torch.float32, device="cuda")
+    out = dec((llr, torch.from_numpy(sx.T.astype(np.int64)).cuda(), torch.from_numpy(sz.T.astype(np.int64)).cuda()))
+    llrx, llry, llrz, x_hat, z_hat, x_logit, z_logit = out
+    assert llrx.shape == (B, c.N) and x_logit.shape == (c.hz.shape[0], B) and z_logit.shape == (c.hx.shape[0], B)
+    assert x_hat.dtype == torch.int64 and z_hat.dtype == torch.float64  # decoding_q.py:788-790
+    o = og.bp4_decode(sx, sz, 32, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
+    assert np.array_equal(o["llr"][:, 0], llrx.cpu().numpy()) and np.array_equal(o["llr"][:, 1], llry.cpu().numpy())
+    assert np.array_equal(o["llr"][:, 2], llrz.cpu().numpy())
+    assert np.array_equal(o["x_hat"], x_hat.cpu().numpy()) and np.array_equal(o["z_hat"], z_hat.cpu().numpy().astype(np.uint8))
+    assert np.array_equal(o["x_logit"].T, x_logit.cpu().numpy()) and np.array_equal(o["z_logit"].T, z_logit.cpu().numpy())
+    # default (non-stage) mode returns (x_hat, z_hat) only; default cn_type is 'boxplus', factor 0.625, 32 iterations
+    dec0 = F.QLDPCBPDecoder(code=c)
+    xh, zh = dec0((llr, torch.from_numpy(sx.T.copy()).cuda(), torch.from_numpy(sz.T.copy()).cuda()))
+    o0 = oracle_graph("ghp882", False).bp4_decode(sx, sz, 32, "boxplus", 0.625, llr_const=llr_const(0.05))
+    assert np.array_equal(o0["x_hat"], xh.cpu().numpy()) and np.array_equal(o0["z_hat"], zh.cpu().numpy().astype(np.uint8))
+
+
+def test_qldpcbpdecoder_errors():
+    c = code("steane")
+    dec = F.QLDPCBPDecoder(code=c, num_iter=4, stage_one=True)
+    sx = torch.zeros((3, 5), dtype=torch.int64, device="cuda")
+    with pytest.raises(TypeError, match="Invalid input dtype"):
+        dec((torch.zeros((5, 3, 7), dtype=torch.float64, device="cuda"), sx, sx))
+    with pytest.raises(ValueError, match="Last dimension must be of length n"):
+        dec((torch.zeros((5, 3, 8), dtype=torch.float32, device="cuda"), sx, sx))
+    with pytest.raises(ValueError):
+        dec((torch.zeros((5, 3, 7), dtype=torch.float32, device="cuda"), sx[:2], sx))
+
+
+def test_stage_two_logit_trace():
+    """trainable/stage_two return mode: llr_hat[2*it], [2*it+1] = soft syndromes after `it` iterations."""
+    name, B, IT = "gb48", 9, 5
+    c = code(name)
+    og, ex, ez, sx, sz = _syndromes(name, 0.06, B)
+    dec = F.QLDPCBPDecoder(code=c, num_iter=IT, normalization_factor=0.8, cn_type="boxplus-phi", stage_two=True)
+    rng = np.random.RandomState(0)
+    llr = rng.uniform(0.5, 4.0, size=(B, 3, c.N)).astype(np.float32)
+    hat, x_hat, z_hat = dec((torch.from_numpy(llr).cuda(), torch.from_numpy(sx.T.copy()).cuda(), torch.from_numpy(sz.T.copy()).cuda()))
+    assert hat.shape == (2 * IT + 2, c.hz.shape[0], B)
+    for it in range(IT + 1):
+        o = og.bp4_decode(sx, sz, it, "boxplus-phi", 0.8, llr_ch=llr)
+        assert np.array_equal(o["x_logit"].T, hat[2 * it].cpu().numpy()), it
+        assert np.array_equal(o["z_logit"].T, hat[2 * it + 1].cpu().numpy()), it
+    assert np.array_equal(o["x_hat"], x_hat.cpu().numpy())
+
+
+def test_feedback_gnn_class_and_weights():
+    c = code("ghp882")
+    B = 6
+    og, ex, ez, sx, sz = _syndromes("ghp882", 0.1, B)
+    G = F.Feedback_GNN(code=c, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean", activation="tanh",
+                       use_bias=True)
+    assert G.count_params() == 3923
+    w0 = G.get_weights()
+    assert np.all(w0[0] == 0) and np.all(w0[1] == 1)  # zeros kernel / ones bias of _llr_inv_embed (feedback_gnn.py:115-116)
+    F.load_weights(G, "./sionna/fec/ldpc/weights/feedback_GNN_n882_k24_wt_4_60_iter_64_16_mixed.npy")
+    w = G.get_weights()
+    o = og.bp4_decode(sx, sz, 64, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
+    h_vn = torch.from_numpy(np.ascontiguousarray(o["llr"].transpose(0, 2, 1))).cuda()  # [bs,n,3]
+    out = G((h_vn, torch.from_numpy(o["z_logit"].T.copy()).cuda(), torch.from_numpy(o["x_logit"].T.copy()).cuda(),
+             torch.from_numpy(sx.T.astype(np.int64)).cuda(), torch.from_numpy(sz.T.astype(np.int64)).cuda()))
+    assert out.shape == (B, c.N, 3)
+    ref = og.feedback_gnn(w, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
+    assert np.array_equal(ref.transpose(0, 2, 1), out.cpu().numpy())
+    with pytest.raises(NotImplementedError):
+        F.Feedback_GNN(code=c, num_msg_dims=16, num_hidden_units=40, num_mlp_layers=2, use_bias=True)
+
+
+def _model(c, iters, compact=False, **kw):
+    d0 = F.QLDPCBPDecoder(code=c, num_iter=iters[0], normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True)
+    decs = [d0] + [F.QLDPCBPDecoder(code=c, num_iter=it, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True,
+                                    graph=d0.graph) for it in iters[1:]]
+    G = F.Feedback_GNN(code=c, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean", activation="tanh",
+                       use_bias=True, graph=d0.graph)
+    F.load_weights(G, WEIGHTS_882)
+    return F.Sandwich_BP_GNN_Evaluation_Model(c, decs, [G] * (len(iters) - 1), num_layers=len(iters), compact=compact, **kw)
+
+
+def test_sandwich_model_call_contract_and_sharding():
+    c = code("ghp882")
+    m = _model(c, [64, 16])
+    s_hat, ls_hat = m(48, 0.1)
+    assert s_hat.shape == (48, 882) and ls_hat.shape == (48, 906) and s_hat.dtype == torch.uint8
+    # successive calls draw fresh samples; two ranks of a world of 2 draw the disjoint halves of the same stream
+    s2, _ = m(48, 0.1)
+    assert not torch.equal(s_hat, s2)
+    a = _model(c, [64, 16], rank=0, world_size=2).decode(24, 0.1)
+    b = _model(c, [64, 16], rank=1, world_size=2).decode(24, 0.1)
+    full = _model(c, [64, 16]).decode(48, 0.1)
+    assert torch.equal(torch.cat([a["noise_x"], b["noise_x"]]), full["noise_x"])
+    assert torch.equal(torch.cat([a["x_hat"], b["x_hat"]]), full["x_hat"])
+    # flagged implies logical (a non-zero syndrome residual is never a stabilizer)
+    assert bool(((s_hat.any(1)) <= (ls_hat.any(1))).all())
+
+
+@pytest.mark.parametrize("p,expect,total", [(0.14, 2375 / 5000, 5000), (0.12, 396 / 5000, 5000), (0.10, 113 / 30000, 30000)])
+def test_published_bler_rows_three_round_sandwich(p, expect, total):
+    """examples/n882.ipynb cell 2: [[882,24]], (64, G,16, G,16, G,16), factor 1.0, p0=0.05.  Same sample counts as
+    the reference's rows; acceptance = binomial 4-sigma band around the published rate (two independent draws)."""
+    c = code("ghp882")
+    m = _model(c, [64, 16, 16, 16], compact=True)
+    counts = torch.zeros(3, dtype=torch.int64, device="cuda")
+    m.mc_step(total, p, counts)
+    fl, bl, n = counts.cpu().numpy()
+    assert n == total and fl == bl  # the reference's table has Flagged == BLER on these rows
+    sigma = np.sqrt(expect * (1 - expect) / total) * np.sqrt(2)
+    assert abs(bl / total - expect) < 4 * sigma + 2 / total, (bl, total, expect)
+
+
+def test_sim_ber_on_gpu_reaches_target():
+    c = code("ghp882")
+    m = _model(c, [64, 16])
+    flagged, bler = F.sim_ber(m, [0.14, 0.12], batch_size=2000, max_mc_iter=20, num_target_block_errors=100, verbose=False)
+    st = F.sim_ber.last
+    assert (st["status"] == 4).all() and (st["block_errors"] >= 100).all()
+    assert 0.3 < bler[0] < 0.85 and 0.03 < bler[1] < 0.3
