@@ -23,6 +23,9 @@ def __getattr__(name):
     if name in ("sim_ber", "count_block_errors", "PlotBER"):
         from . import utils as _u
         return getattr(_u, name)
+    if name == "GNN_BP4":
+        from .gnn import GNN_BP4
+        return GNN_BP4
     if name in ("TannerGraph", "GnnWeights"):
         from . import graph as _g
         return getattr(_g, name)

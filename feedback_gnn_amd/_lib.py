@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfgnn_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 CN_TYPES = {"boxplus": 0, "boxplus-phi": 1, "minsum": 2}
-ROWS_X_LOGIT, ROWS_Z_LOGIT, ROWS_HX_PERP, ROWS_HZ_PERP = 0, 1, 2, 3
+ROWS_X_LOGIT, ROWS_Z_LOGIT, ROWS_HX_PERP, ROWS_HZ_PERP, ROWS_LX, ROWS_LZ = 0, 1, 2, 3, 4, 5
 
 
 class FgnnError(RuntimeError):
@@ -58,6 +58,11 @@ _SIGNATURES = {
     "fgnn_sandwich_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                        C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "fgnn_gnnbp4_weights_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "fgnn_gnnbp4_weights_destroy": (None, [C.c_void_p]),
+    "fgnn_gnnbp4_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "fgnn_gnnbp4_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6
+                           + [C.c_size_t, C.c_void_p]),
 }
 
 ABI_SYMBOLS = tuple(_SIGNATURES)

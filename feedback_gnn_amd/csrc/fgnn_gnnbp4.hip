@@ -1,0 +1,329 @@
+// fgnn_gnnbp4.hip — the syndrome-only "full GNN" decoder GNN_BP4 (BASELINE.json configs[4]).
+//
+// Replaces GNN_BP4.call of /root/reference sionna/fec/ldpc/gnn.py:383-423 with UpdateCNEmbeddings.call
+// (:573-610), UpdateVNEmbeddings.call (:714-751), cal_logit (:291-314) and make_hard_decision (:359-367)
+// for num_mlp_layers = 2, activation tanh, reduce_op mean, use_bias True, D = num_embed_dims = 20,
+// H = num_hidden_units = 40.  The reference raises as shipped (call unpacks 5 values from cal_logit's 4,
+// :408 vs :314) and has no trained weights; the behaviour implemented is the oracle's (og_gnn_bp4), which
+// repairs that line and restates the list-aliasing quirk (message width = num_embed_dims).
+//
+// One workgroup per codeword; node embeddings live in a caller-provided global workspace (203 KB per
+// [[1270,28]] codeword — too large for LDS, but L2/MALL-resident while the workgroup runs) and are updated in
+// place: a node's new embedding depends on its own old one and on the OTHER side's embeddings only.  One thread
+// per receiving node runs the edge MLP (2D -> H tanh -> D) for each incoming edge, the mean, and the embed MLP,
+// with wave-uniform weights arriving through scalar loads (rows made contiguous at upload).  Arithmetic order is
+// the oracle's: fmaf chains in ascending k from 0, + bias, ascending-edge sums / count.
+#include <cstring>
+
+#include "fgnn_internal.h"
+#include "fgnn_math.h"
+
+namespace {
+
+constexpr int D = 20;
+constexpr int H = 40;
+
+struct MlpDev {
+    const float* w1t;  // [H][nin_pad]  (W1 transposed; row j = the weights of hidden unit j)
+    const float* b1;   // [H]
+    const float* w2;   // [H][D]
+    const float* b2;   // [D]
+};
+
+struct GnnBp4Dev {
+    MlpDev cn_msg[2], cn_embed[2], vn_msg[2], vn_embed;
+    const float* winv;  // [D][4]
+    const float* binv;  // [4]
+};
+
+template <int NIN, int NPAD>
+__device__ __forceinline__ void mlp2(const float (&in)[NIN], const MlpDev& m, float (&out)[D])
+{
+#pragma unroll
+    for (int i = 0; i < D; ++i) out[i] = 0.0f;
+#pragma unroll 1
+    for (int j = 0; j < H; ++j) {
+        const float* r = m.w1t + j * NPAD;
+        float a = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) a = FG_FMA(in[k], r[k], a);
+        const float h = fg_tanh(a + m.b1[j]);
+        const float* r2 = m.w2 + j * D;
+#pragma unroll
+        for (int i = 0; i < D; ++i) out[i] = FG_FMA(h, r2[i], out[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) out[i] = out[i] + m.b2[i];
+}
+
+__device__ __forceinline__ float logit_row_gnn(const float* llr, const int* __restrict__ col, int deg)
+{
+    unsigned neg = 0;
+    float T = 0.0f;
+    for (int j = 0; j < deg; ++j) {
+        float v = llr[col[j]];
+        neg ^= (v < 0.0f);
+        T = T + fg_phi_gnn(FG_ABS(v));
+    }
+    const float o = fg_phi_gnn(T);
+    return neg ? -o : o;
+}
+
+struct Args {
+    int B, num_iter;
+    const uint8_t* synd_x;
+    const uint8_t* synd_z;
+    uint8_t* x_hat;
+    uint8_t* z_hat;
+    float* llr_out;   // [B,3,n]
+    float* xlog_all;  // [num_iter,B,m_z+rows(lz)] or null
+    float* zlog_all;  // [num_iter,B,m_x+rows(lx)] or null
+    float* work;      // [B,(n+m)*D]
+};
+
+__global__ void __launch_bounds__(256) gnn_bp4_kernel(GraphDev g, GnnBp4Dev w, Args a)
+{
+    extern __shared__ float lds[];
+    const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+    const int n = g.n, mx = g.m_x, m = g.m;
+    float* lx = lds;          // [n]   llr_x of cal_logit
+    float* lz = lx + n;       // [n]   llr_z
+    float* hlog = lz + n;     // [m]   hx_logit then hz_logit
+    float* hv = a.work + (size_t)b * (size_t)(n + m) * D;
+    float* hc = hv + (size_t)n * D;
+    const uint8_t* sx = a.synd_x + (size_t)b * mx;
+    const uint8_t* sz = a.synd_z + (size_t)b * g.m_z;
+    const int rxp = g.m_z + g.rows[5], rzp = g.m_x + g.rows[4];
+    for (int i = tid; i < n * D; i += T) hv[i] = 1.0f;  // (:396)
+    for (int i = tid; i < m * D; i += T) hc[i] = 0.0f;  // (:392-393)
+    for (int c = tid; c < m; c += T) hlog[c] = 0.0f;    // zero logits for the first CN update (:400-401)
+    __syncthreads();
+    float* llr = a.llr_out + (size_t)b * 3 * n;
+    for (int it = -1; it < a.num_iter; ++it) {
+        if (it >= 0) {
+            // ---- UpdateVNEmbeddings (:714-751) + llr / binary LLRs of cal_logit (:291-304) ----
+            for (int v = tid; v < n; v += T) {
+                float own[D], feat3[3 * D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) own[i] = hv[(size_t)v * D + i];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int* vptr = s ? g.vptr_z : g.vptr_x;
+                    const int e0 = vptr[v], e1 = vptr[v + 1];
+                    float acc[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) acc[i] = 0.0f;
+                    for (int e = e0; e < e1; ++e) {
+                        const int c = g.vchk[e];  // side-local check id
+                        const float* src = hc + (size_t)((s ? mx : 0) + c) * D;
+                        float feat[2 * D], msg[D];
+#pragma unroll
+                        for (int i = 0; i < D; ++i) { feat[i] = src[i]; feat[D + i] = own[i]; }
+                        mlp2<2 * D, 2 * D>(feat, w.vn_msg[s], msg);
+                        const float sg = ((s ? sz[c] : sx[c]) & 1) ? -1.0f : 1.0f;
+#pragma unroll
+                        for (int i = 0; i < D; ++i) { const float mv = msg[i] * sg; acc[i] = (e == e0) ? mv : acc[i] + mv; }
+                    }
+                    if (e1 > e0) {
+                        const float fd = (float)(e1 - e0);
+#pragma unroll
+                        for (int i = 0; i < D; ++i) acc[i] = acc[i] / fd;
+                    }
+#pragma unroll
+                    for (int i = 0; i < D; ++i) feat3[s * D + i] = acc[i];
+                }
+#pragma unroll
+                for (int i = 0; i < D; ++i) feat3[2 * D + i] = own[i];
+                float nh[D];
+                mlp2<3 * D, 3 * D>(feat3, w.vn_embed, nh);
+                float L[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    hv[(size_t)v * D + k] = nh[k];
+                    L[0] = FG_FMA(nh[k], w.winv[k * 4 + 0], L[0]);
+                    L[1] = FG_FMA(nh[k], w.winv[k * 4 + 1], L[1]);
+                    L[2] = FG_FMA(nh[k], w.winv[k * 4 + 2], L[2]);
+                }
+                L[0] = L[0] + w.binv[0];
+                L[1] = L[1] + w.binv[1];
+                L[2] = L[2] + w.binv[2];
+                llr[v] = L[0];
+                llr[n + v] = L[1];
+                llr[2 * n + v] = L[2];
+                lz[v] = fg_softplus(-L[0]) - fg_lse2(-L[2], -L[1]);
+                lx[v] = fg_softplus(-L[2]) - fg_lse2(-L[0], -L[1]);
+            }
+            __syncthreads();
+            // ---- soft syndromes (:306-314): hx rows use llr_z, hz rows use llr_x; logical rows appended ----
+            float* xl = a.xlog_all ? a.xlog_all + ((size_t)it * a.B + b) * rxp : nullptr;
+            float* zl = a.zlog_all ? a.zlog_all + ((size_t)it * a.B + b) * rzp : nullptr;
+            for (int c = tid; c < m; c += T) {
+                const int p0 = g.cptr[c];
+                const float vq = logit_row_gnn(c < mx ? lz : lx, g.cvn + p0, g.cptr[c + 1] - p0);
+                hlog[c] = vq;
+                if (c < mx) { if (zl) zl[c] = vq; }
+                else if (xl) xl[c - mx] = vq;
+            }
+            if (xl)
+                for (int r = tid; r < g.rows[5]; r += T)
+                    xl[g.m_z + r] = logit_row_gnn(lx, g.rcol[5] + g.rptr[5][r], g.rptr[5][r + 1] - g.rptr[5][r]);
+            if (zl)
+                for (int r = tid; r < g.rows[4]; r += T)
+                    zl[g.m_x + r] = logit_row_gnn(lz, g.rcol[4] + g.rptr[4][r], g.rptr[4][r + 1] - g.rptr[4][r]);
+            __syncthreads();
+            if (it == a.num_iter - 1) break;  // (:414-415)
+        }
+        // ---- UpdateCNEmbeddings (:573-610) ----
+        for (int c = tid; c < m; c += T) {
+            const int s = c >= mx;
+            const int p0 = g.cptr[c], p1 = g.cptr[c + 1];
+            float* hto = hc + (size_t)c * D;
+            float own[D], acc[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) { own[i] = hto[i]; acc[i] = 0.0f; }
+            for (int jx = p0; jx < p1; ++jx) {
+                const float* src = hv + (size_t)g.cvn[jx] * D;
+                float feat[2 * D], msg[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) { feat[i] = src[i]; feat[D + i] = own[i]; }
+                mlp2<2 * D, 2 * D>(feat, w.cn_msg[s], msg);
+#pragma unroll
+                for (int i = 0; i < D; ++i) acc[i] = (jx == p0) ? msg[i] : acc[i] + msg[i];
+            }
+            if (p1 > p0) {
+                const float fd = (float)(p1 - p0);
+#pragma unroll
+                for (int i = 0; i < D; ++i) acc[i] = acc[i] / fd;
+            }
+            float feat[2 * D + 1], nh[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) { feat[i] = acc[i]; feat[D + i] = own[i]; }
+            const unsigned sb = (s ? sz[c - mx] : sx[c]) & 1;
+            feat[2 * D] = (it >= 0) ? hlog[c] * (sb ? -1.0f : 1.0f) : 0.0f;  // (:417-418)
+            mlp2<2 * D + 1, 2 * D + 4>(feat, w.cn_embed[s], nh);
+#pragma unroll
+            for (int i = 0; i < D; ++i) hto[i] = nh[i];
+        }
+        __syncthreads();
+    }
+    for (int v = tid; v < n; v += T) {  // make_hard_decision (:359-367)
+        const float X = llr[v], Y = llr[n + v], Z = llr[2 * n + v];
+        int d = 0;
+        float best = 0.0f;
+        if (X < best) { best = X; d = 1; }
+        if (Z < best) { best = Z; d = 2; }
+        if (Y < best) { best = Y; d = 3; }
+        a.x_hat[(size_t)b * n + v] = (uint8_t)(d & 1);
+        a.z_hat[(size_t)b * n + v] = (uint8_t)(d >> 1);
+    }
+}
+
+}  // namespace
+
+struct fgnn_gnnbp4_weights {
+    GnnBp4Dev d;
+    int device;
+    void* blob;
+};
+
+extern "C" int fgnn_gnnbp4_weights_create(const float* const host_arrays[30], int num_embed_dims, int num_hidden_units,
+                                          int device, fgnn_gnnbp4_weights** out)
+{
+    if (!host_arrays || !out) return fgnn_fail(FGNN_ERR_ARG, "NULL argument");
+    if (num_embed_dims != D || num_hidden_units != H)
+        return fgnn_fail(FGNN_ERR_ARG, "the GNN_BP4 kernel is built for num_embed_dims=20, num_hidden_units=40");
+    for (int i = 0; i < 30; ++i)
+        if (!host_arrays[i]) return fgnn_fail(FGNN_ERR_ARG, "weight array is NULL");
+    FGNN_HIP_CHECK(hipSetDevice(device));
+    std::vector<float> h;
+    auto push = [&](size_t count) {
+        size_t o = h.size();
+        h.resize(o + ((count + 3) & ~size_t(3)), 0.0f);
+        return o;
+    };
+    const int nin[7] = {2 * D, 2 * D, 2 * D + 1, 2 * D + 1, 2 * D, 2 * D, 3 * D};
+    const int npad[7] = {2 * D, 2 * D, 2 * D + 4, 2 * D + 4, 2 * D, 2 * D, 3 * D};
+    size_t off[7][4];
+    for (int q = 0; q < 7; ++q) {
+        const float* const* a = host_arrays + 4 * q;
+        off[q][0] = push((size_t)H * npad[q]);
+        for (int j = 0; j < H; ++j)
+            for (int k = 0; k < nin[q]; ++k) h[off[q][0] + (size_t)j * npad[q] + k] = a[0][(size_t)k * H + j];
+        off[q][1] = push(H);
+        std::memcpy(&h[off[q][1]], a[1], H * sizeof(float));
+        off[q][2] = push((size_t)H * D);
+        std::memcpy(&h[off[q][2]], a[2], (size_t)H * D * sizeof(float));
+        off[q][3] = push(D);
+        std::memcpy(&h[off[q][3]], a[3], D * sizeof(float));
+    }
+    const size_t owi = push((size_t)D * 4), obi = push(4);
+    for (int k = 0; k < D; ++k)
+        for (int i = 0; i < 3; ++i) h[owi + k * 4 + i] = host_arrays[28][k * 3 + i];
+    std::memcpy(&h[obi], host_arrays[29], 3 * sizeof(float));
+    fgnn_gnnbp4_weights* w = new fgnn_gnnbp4_weights();
+    w->device = device;
+    w->blob = nullptr;
+    hipError_t e = hipMalloc(&w->blob, h.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(w->blob, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (w->blob) (void)hipFree(w->blob);
+        delete w;
+        return fgnn_fail(FGNN_ERR_HIP, std::string("GNN_BP4 weights upload: ") + hipGetErrorString(e));
+    }
+    const float* base = static_cast<const float*>(w->blob);
+    MlpDev* dst[7] = {&w->d.cn_msg[0], &w->d.cn_msg[1], &w->d.cn_embed[0], &w->d.cn_embed[1], &w->d.vn_msg[0], &w->d.vn_msg[1],
+                      &w->d.vn_embed};
+    for (int q = 0; q < 7; ++q) {
+        dst[q]->w1t = base + off[q][0];
+        dst[q]->b1 = base + off[q][1];
+        dst[q]->w2 = base + off[q][2];
+        dst[q]->b2 = base + off[q][3];
+    }
+    w->d.winv = base + owi;
+    w->d.binv = base + obi;
+    *out = w;
+    return FGNN_OK;
+}
+
+extern "C" void fgnn_gnnbp4_weights_destroy(fgnn_gnnbp4_weights* w)
+{
+    if (!w) return;
+    (void)hipSetDevice(w->device);
+    if (w->blob) (void)hipFree(w->blob);
+    delete w;
+}
+
+extern "C" size_t fgnn_gnnbp4_workspace_bytes(const fgnn_graph* g, int B)
+{
+    if (!g || B <= 0) return 0;
+    return (size_t)B * (size_t)(g->d.n + g->d.m) * D * sizeof(float);
+}
+
+extern "C" int fgnn_gnnbp4_decode(const fgnn_graph* g, const fgnn_gnnbp4_weights* w, int num_iter, const uint8_t* synd_x,
+                                  const uint8_t* synd_z, int B, uint8_t* x_hat, uint8_t* z_hat, float* llr_out,
+                                  float* x_logit_all, float* z_logit_all, void* workspace, size_t ws_bytes, void* stream)
+{
+    if (!g || !w) return fgnn_fail(FGNN_ERR_ARG, "graph or weights is NULL");
+    if (num_iter < 1 || B < 0) return fgnn_fail(FGNN_ERR_ARG, "num_iter must be >= 1 and B >= 0");
+    if (!synd_x || !synd_z || !x_hat || !z_hat || !llr_out) return fgnn_fail(FGNN_ERR_ARG, "required buffer is NULL");
+    if (!g->d.rptr[4] || !g->d.rptr[5]) return fgnn_fail(FGNN_ERR_STATE, "lx / lz row sets not installed (fgnn_graph_set_rows 4, 5)");
+    if (w->device != g->device) return fgnn_fail(FGNN_ERR_ARG, "weights and graph live on different devices");
+    if (B == 0) return FGNN_OK;
+    if (!workspace || ws_bytes < fgnn_gnnbp4_workspace_bytes(g, B)) return fgnn_fail(FGNN_ERR_ARG, "workspace too small");
+    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    Args a;
+    a.B = B;
+    a.num_iter = num_iter;
+    a.synd_x = synd_x;
+    a.synd_z = synd_z;
+    a.x_hat = x_hat;
+    a.z_hat = z_hat;
+    a.llr_out = llr_out;
+    a.xlog_all = x_logit_all;
+    a.zlog_all = z_logit_all;
+    a.work = static_cast<float*>(workspace);
+    const size_t lds_bytes = (size_t)(2 * g->d.n + g->d.m) * sizeof(float);
+    hipLaunchKernelGGL(gnn_bp4_kernel, dim3(B), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), g->d, w->d, a);
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}

@@ -196,7 +196,7 @@ extern "C" void fgnn_graph_destroy(fgnn_graph* g)
 
 extern "C" int fgnn_graph_set_rows(fgnn_graph* g, int which, int rows, int nnz, const int32_t* row, const int32_t* col)
 {
-    if (!g || which < 0 || which > 3 || rows < 0 || nnz < 0) return fgnn_fail(FGNN_ERR_ARG, "bad row-set arguments");
+    if (!g || which < 0 || which > 5 || rows < 0 || nnz < 0) return fgnn_fail(FGNN_ERR_ARG, "bad row-set arguments");
     for (int i = 0; i < nnz; ++i)
         if (row[i] < 0 || row[i] >= rows || col[i] < 0 || col[i] >= g->d.n)
             return fgnn_fail(FGNN_ERR_ARG, "row-set index out of range");

@@ -20,9 +20,9 @@ struct GraphDev {
     const int* cvn;     // [E]   qubit of that edge
     const uint16_t* cslot16;  // [m][8] packed slot rows for DC-regular graphs with DC <= 8 and E < 65536, else null
     // CSR row sets (fgnn_graph_set_rows)
-    int rows[4];
-    const int* rptr[4];
-    const int* rcol[4];
+    int rows[6];
+    const int* rptr[6];
+    const int* rcol[6];
     // uniform degrees, 0 if irregular
     int dvx, dvz, dc;
 };
@@ -37,7 +37,7 @@ struct fgnn_graph {
     std::vector<void*> allocs;
     // host copies of the canonical edge lists (fgnn_graph_edges)
     std::vector<int32_t> h_chk[2], h_var[2];
-    void* row_alloc[4][2];
+    void* row_alloc[6][2];
     // optional per-launch timing of the BP4 kernel with HIP events on the launch stream (fgnn_profile_*)
     mutable bool prof_on = false;
     mutable int prof_n = 0;

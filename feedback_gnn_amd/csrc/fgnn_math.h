@@ -155,6 +155,14 @@ FG_FN float fg_phi(float x)
     return sp - fg_log(y - 1.0f);
 }
 
+/* GNN_BP4._phi, sionna/fec/ldpc/gnn.py:333-338: same clip, but log(exp(x)+1) - log(exp(x)-1) (no softplus). */
+FG_FN float fg_phi_gnn(float x)
+{
+    float xc = FG_MIN(FG_MAX(x, FG_PHI_MIN), FG_PHI_MAX);
+    float y = fg_exp(xc);
+    return fg_log(y + 1.0f) - fg_log(y - 1.0f);
+}
+
 /* ---- tanh / atanh (feedback-GNN activations, 'boxplus' check-node rule) ------------------ */
 FG_FN float fg_tanh(float x)
 {

@@ -1,0 +1,71 @@
+"""GNN_BP4 — the syndrome-only "full GNN" decoder on MI355X (BASELINE.json configs[4]).
+
+Drop-in for `sionna.fec.ldpc.GNN_BP4` (/root/reference sionna/fec/ldpc/gnn.py:71-423) for the configuration of
+SURVEY.md §8d: num_embed_dims=20, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean",
+activation="tanh", use_bias=True.  The reference's `call` raises as shipped (it unpacks five values from
+`cal_logit`, which returns four, gnn.py:408 vs :314) and no trained weights exist; this class implements the repaired
+semantics of the oracle (oracle/fgnn_oracle.c: og_gnn_bp4) and initialises weights like Keras would (glorot-uniform
+kernels, ones biases, zero kernel for `_llr_inv_embed`).
+"""
+import numpy as np
+import torch
+
+from .graph import GNNBP4_SHAPES, GnnBp4Weights, TannerGraph
+
+
+class GNN_BP4:
+    """``decoder((syndrome_x[bs,m_x], syndrome_z[bs,m_z]))`` → ``(llr_hat, x_hat[n,bs], z_hat[n,bs])`` where ``llr_hat`` is a
+    list with one ``(x_perp_logit[m_z+k,bs], z_perp_logit[m_x+k,bs])`` pair per iteration (gnn.py:409)."""
+
+    def __init__(self, code, num_embed_dims, num_msg_dims, num_hidden_units, num_mlp_layers, num_iter, reduce_op="mean",
+                 activation="tanh", clip_llr_to=None, use_attributes=False, node_attribute_dims=0, msg_attribute_dims=0,
+                 use_bias=False, input_embed=False, loss_type="boxplus-phi", device=None, graph=None, seed=0):
+        cfg = (int(num_embed_dims), int(num_hidden_units), int(num_mlp_layers), reduce_op, activation, bool(use_bias),
+               bool(use_attributes), loss_type)
+        if cfg != (20, 40, 2, "mean", "tanh", True, False, "boxplus-phi"):
+            raise NotImplementedError("the gfx950 kernel is built for num_embed_dims=20, num_hidden_units=40, num_mlp_layers=2, "
+                                      f"reduce_op='mean', activation='tanh', use_bias=True, no attributes; got {cfg}")
+        # num_msg_dims is accepted but irrelevant: the reference overwrites units[-1] with num_embed_dims in the list
+        # the message MLPs share (gnn.py:548, :690), so messages have num_embed_dims components.
+        self._num_msg_dims = int(num_msg_dims)
+        self._num_iter = int(num_iter)
+        self.graph = graph if graph is not None else TannerGraph(code, stage_one=True, device=device)
+        rng = np.random.RandomState(seed)
+        w = []
+        for shp in GNNBP4_SHAPES:
+            if len(shp) == 1:
+                w.append(np.ones(shp, np.float32))
+            else:
+                lim = np.sqrt(6.0 / (shp[0] + shp[1]))
+                w.append(rng.uniform(-lim, lim, size=shp).astype(np.float32))
+        w[28] = np.zeros(GNNBP4_SHAPES[28], np.float32)
+        self._weights = None
+        self.set_weights(w)
+
+    @property
+    def num_iter(self):
+        return self._num_iter
+
+    @num_iter.setter
+    def num_iter(self, value):
+        self._num_iter = int(value)
+
+    def get_weights(self):
+        return [a.copy() for a in self._weights.arrays]
+
+    def set_weights(self, weights):
+        self._weights = GnnBp4Weights(list(weights), self.graph.device)
+
+    def __call__(self, inputs):
+        syndrome_x, syndrome_z = inputs
+        g = self.graph
+
+        def prep(s, rows):
+            s = torch.as_tensor(s, device=g.device)
+            if s.dim() != 2 or s.shape[1] != rows:
+                raise ValueError(f"syndrome must have shape [batch_size, {rows}], got {tuple(s.shape)}")
+            return (s.to(torch.int64) & 1).to(torch.uint8).contiguous()
+
+        out = g.gnn_bp4_decode(self._weights, prep(syndrome_x, g.m_x), prep(syndrome_z, g.m_z), self._num_iter)
+        llr_hat = [(out["x_logit_all"][i].t(), out["z_logit_all"][i].t()) for i in range(self._num_iter)]
+        return llr_hat, out["x_hat"].t().to(torch.int64), out["z_hat"].t().to(torch.float64)

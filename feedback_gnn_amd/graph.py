@@ -83,7 +83,8 @@ class TannerGraph:
         xp, zp = (hz, hx) if stage_one else (np.asarray(code.hx_perp), np.asarray(code.hz_perp))
         self.rows_xp, self.rows_zp = int(xp.shape[0]), int(zp.shape[0])
         self.rows_hxp, self.rows_hzp = int(code.hx_perp.shape[0]), int(code.hz_perp.shape[0])
-        for which, mat in ((0, xp), (1, zp), (2, code.hx_perp), (3, code.hz_perp)):
+        self.rows_lx, self.rows_lz = int(np.asarray(code.lx).shape[0]), int(np.asarray(code.lz).shape[0])
+        for which, mat in ((0, xp), (1, zp), (2, code.hx_perp), (3, code.hz_perp), (4, code.lx), (5, code.lz)):
             r, c = _coo(mat)
             check(L.fgnn_graph_set_rows(self.handle, which, int(np.asarray(mat).shape[0]), len(r), _np_ptr(r), _np_ptr(c)))
 
@@ -277,3 +278,47 @@ class TannerGraph:
         if return_rounds:
             out["rounds"] = rounds
         return out
+
+    # ---- GNN_BP4 -----------------------------------------------------------------------------------------
+    def gnn_bp4_decode(self, weights, synd_x, synd_z, num_iter, return_logits=True, workspace=None):
+        B = int(synd_x.shape[0])
+        synd_x = self._chk(synd_x, (B, self.m_x), torch.uint8, "synd_x")
+        synd_z = self._chk(synd_z, (B, self.m_z), torch.uint8, "synd_z")
+        nbytes = _lib.lib().fgnn_gnnbp4_workspace_bytes(self.handle, B)
+        if workspace is None:
+            workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        xh = self._new((B, self.n), torch.uint8)
+        zh = self._new((B, self.n), torch.uint8)
+        llr = self._new((B, 3, self.n), torch.float32)
+        xl = self._new((num_iter, B, self.m_z + self.rows_lz), torch.float32) if return_logits else None
+        zl = self._new((num_iter, B, self.m_x + self.rows_lx), torch.float32) if return_logits else None
+        check(_lib.lib().fgnn_gnnbp4_decode(self.handle, weights.handle, int(num_iter), _ptr(synd_x), _ptr(synd_z), B, _ptr(xh),
+                                            _ptr(zh), _ptr(llr), _ptr(xl), _ptr(zl), _ptr(workspace), workspace.numel(),
+                                            _stream(self.device)))
+        return dict(x_hat=xh, z_hat=zh, llr=llr, x_logit_all=xl, z_logit_all=zl)
+
+
+GNNBP4_SHAPES = ([(40, 40), (40,), (40, 20), (20,)] * 2 + [(41, 40), (40,), (40, 20), (20,)] * 2 + [(40, 40), (40,), (40, 20), (20,)] * 2
+                 + [(60, 40), (40,), (40, 20), (20,)] + [(20, 3), (3,)])
+
+
+class GnnBp4Weights:
+    """Device copy of one GNN_BP4 parameter set (30 arrays, order of fgnn.h)."""
+
+    def __init__(self, arrays, device):
+        arrays = [np.ascontiguousarray(a, dtype=np.float32) for a in arrays]
+        if [a.shape for a in arrays] != GNNBP4_SHAPES:
+            raise ValueError(f"GNN_BP4 weights must have shapes {GNNBP4_SHAPES}")
+        self.arrays = arrays
+        self.device = torch.device(device)
+        ptrs = (C.c_void_p * 30)(*[a.ctypes.data for a in arrays])
+        h = C.c_void_p()
+        check(_lib.lib().fgnn_gnnbp4_weights_create(ptrs, 20, 40, self.device.index or 0, C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.lib().fgnn_gnnbp4_weights_destroy(self.handle)
+        except Exception:
+            pass

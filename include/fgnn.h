@@ -29,9 +29,10 @@ extern "C" {
 
 typedef struct fgnn_graph fgnn_graph;     /* Tanner graphs + row sets of one CSS code, on one device */
 typedef struct fgnn_weights fgnn_weights; /* one feedback GNN's 3 923 parameters, on one device */
+typedef struct fgnn_gnnbp4_weights fgnn_gnnbp4_weights; /* parameters of one GNN_BP4 decoder, on one device */
 
 enum { FGNN_CN_BOXPLUS = 0, FGNN_CN_BOXPLUS_PHI = 1, FGNN_CN_MINSUM = 2 }; /* decoding_q.py:97-107 */
-enum { FGNN_ROWS_X_LOGIT = 0, FGNN_ROWS_Z_LOGIT = 1, FGNN_ROWS_HX_PERP = 2, FGNN_ROWS_HZ_PERP = 3 };
+enum { FGNN_ROWS_X_LOGIT = 0, FGNN_ROWS_Z_LOGIT = 1, FGNN_ROWS_HX_PERP = 2, FGNN_ROWS_HZ_PERP = 3, FGNN_ROWS_LX = 4, FGNN_ROWS_LZ = 5 };
 
 enum {
     FGNN_OK = 0,
@@ -54,7 +55,9 @@ void fgnn_graph_destroy(fgnn_graph* g);
  *   FGNN_ROWS_X_LOGIT / Z_LOGIT : pcm_x_perp / pcm_z_perp of decoding_q.py:33-37,93-94
  *                                 (hz / hx when stage_one or stage_two, else hx_perp / hz_perp);
  *   FGNN_ROWS_HX_PERP / HZ_PERP : code.hx_perp / code.hz_perp for the residual check,
- *                                 feedback_gnn.py:352-353. */
+ *                                 feedback_gnn.py:352-353;
+ *   FGNN_ROWS_LX / LZ           : code.lx / code.lz, the logical rows appended to the soft syndromes of
+ *                                 GNN_BP4.cal_logit, gnn.py:305-313. */
 int fgnn_graph_set_rows(fgnn_graph* g, int which, int rows, int nnz, const int32_t* row, const int32_t* col);
 
 /* Launch geometry of the LDS-resident kernels: threads per codeword and codewords per workgroup.
@@ -139,6 +142,21 @@ int fgnn_sandwich_decode(const fgnn_graph* g, int num_layers, const int32_t* ite
                          const uint8_t* synd_x, const uint8_t* synd_z, int B, int compact, uint8_t* x_hat,
                          uint8_t* z_hat, float* llr_final, uint8_t* rounds, void* workspace, size_t ws_bytes,
                          void* stream);
+
+/* GNN_BP4 (the syndrome-only "full GNN" decoder), sionna/fec/ldpc/gnn.py:71-423 with UpdateCNEmbeddings (:426-610)
+ * and UpdateVNEmbeddings (:612-751): num_mlp_layers=2, tanh, mean, use_bias, num_embed_dims=20, num_hidden_units=40.
+ * Weights: 30 host arrays — cn_msg_x, cn_msg_z, cn_embed_x, cn_embed_z, vn_msg_x, vn_msg_z, vn_embed, each
+ * {W1[in,40], b1[40], W2[40,20], b2[20]} with in = 40, 40, 41, 41, 40, 40, 60, then llr_inv {W[20,3], b[3]}.
+ * Outputs: x_hat/z_hat [B,n] (make_hard_decision :359-367), llr_out [B,3,n] = last embed_to_llr (:283-289),
+ * x_logit_all [num_iter,B,m_z+rows(lz)], z_logit_all [num_iter,B,m_x+rows(lx)] = llr_hat of :409 (may be NULL).
+ * The reference's call raises as shipped (:408 unpacks 5 of cal_logit's 4 values); that line is repaired. */
+int fgnn_gnnbp4_weights_create(const float* const host_arrays[30], int num_embed_dims, int num_hidden_units, int device,
+                               fgnn_gnnbp4_weights** out);
+void fgnn_gnnbp4_weights_destroy(fgnn_gnnbp4_weights* w);
+size_t fgnn_gnnbp4_workspace_bytes(const fgnn_graph* g, int B);
+int fgnn_gnnbp4_decode(const fgnn_graph* g, const fgnn_gnnbp4_weights* w, int num_iter, const uint8_t* synd_x,
+                       const uint8_t* synd_z, int B, uint8_t* x_hat, uint8_t* z_hat, float* llr_out, float* x_logit_all,
+                       float* z_logit_all, void* workspace, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

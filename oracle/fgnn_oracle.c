@@ -59,6 +59,7 @@ typedef struct og_graph {
     int* cvn[2];   /* [E]  qubit id of that edge */
     og_csr logit_rows[2]; /* pcm_x_perp, pcm_z_perp of QLDPCBPDecoder (decoding_q.py:33-37) */
     og_csr perp[2];       /* hx_perp, hz_perp for the residual check (feedback_gnn.py:352-353) */
+    og_csr logical[2];    /* lx, lz (GNN_BP4.cal_logit, gnn.py:305-313) */
 } og_graph;
 
 static void csr_free(og_csr* c)
@@ -119,10 +120,10 @@ og_graph* og_graph_create(int n, int m_x, int m_z, int E_x, const int32_t* chk_x
     return g;
 }
 
-/* which: 0 = pcm_x_perp (x_logit rows), 1 = pcm_z_perp (z_logit rows), 2 = hx_perp, 3 = hz_perp */
+/* which: 0 = pcm_x_perp (x_logit rows), 1 = pcm_z_perp (z_logit rows), 2 = hx_perp, 3 = hz_perp, 4 = lx, 5 = lz */
 void og_graph_set_rows(og_graph* g, int which, int rows, int nnz, const int32_t* r, const int32_t* c)
 {
-    og_csr* dst = which < 2 ? &g->logit_rows[which] : &g->perp[which - 2];
+    og_csr* dst = which < 2 ? &g->logit_rows[which] : (which < 4 ? &g->perp[which - 2] : &g->logical[which - 4]);
     csr_from_coo(dst, rows, nnz, r, c);
 }
 
@@ -137,6 +138,7 @@ void og_graph_destroy(og_graph* g)
         free(g->cvn[s]);
         csr_free(&g->logit_rows[s]);
         csr_free(&g->perp[s]);
+        csr_free(&g->logical[s]);
     }
     free(g);
 }
@@ -615,6 +617,169 @@ int og_sandwich_decode(const og_graph* g, int num_layers, const int* iters, cons
         free(zl);
         free(work);
         free(xu);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * GNN_BP4.call, sionna/fec/ldpc/gnn.py:383-423 with UpdateCNEmbeddings.call (:573-610) and
+ * UpdateVNEmbeddings.call (:714-751), 2-layer MLPs (Dense(H, tanh) -> Dense(D)).  Reference quirks
+ * restated or repaired: (i) cal_logit returns 4 values but call unpacks 5 (:408 vs :314) —
+ * repaired: the 4 values are used; (ii) `units[-1] = num_embed_dims` (:548, :690) aliases the list handed to
+ * the message MLPs before they are built, so messages have num_embed_dims (= D) components — restated;
+ * (iii) syndromes are [bs, m] here; (iv) no trained weights exist.
+ * Weight list (30 arrays): cn_msg_x, cn_msg_z, cn_embed_x, cn_embed_z, vn_msg_x, vn_msg_z, vn_embed — each
+ * {W1[in,H], b1[H], W2[H,D], b2[D]} with in = 2D, 2D, 2D+1, 2D+1, 2D, 2D, 3D — then llr_inv {W[D,3], b[3]}.
+ * Every Dense is an fmaf chain in ascending k from 0, then + bias; means = ascending-edge sums / count.
+ * ------------------------------------------------------------------------------------------ */
+static void mlp2(const float* in, int nin, const float* W1, const float* b1, const float* W2, const float* b2, int H, int D,
+                 float* out)
+{
+    for (int i = 0; i < D; ++i) out[i] = 0.0f;
+    for (int j = 0; j < H; ++j) {
+        float a = 0.0f;
+        for (int k = 0; k < nin; ++k) a = FG_FMA(in[k], W1[k * H + j], a);
+        const float h = fg_tanh(a + b1[j]);
+        for (int i = 0; i < D; ++i) out[i] = FG_FMA(h, W2[j * D + i], out[i]);
+    }
+    for (int i = 0; i < D; ++i) out[i] = out[i] + b2[i];
+}
+
+static float logit_row_gnn(const int* col, int deg, const float* llr) /* _cn_update_phi_loss, gnn.py:341-357 */
+{
+    int neg = 0;
+    float T = 0.0f;
+    for (int j = 0; j < deg; ++j) {
+        float v = llr[col[j]];
+        neg ^= (v < 0.0f);
+        T = T + fg_phi_gnn(FG_ABS(v));
+    }
+    float out = fg_phi_gnn(T);
+    return neg ? -out : out;
+}
+
+#define GB_MAXD 64
+static void gnn_bp4_one(const og_graph* g, const float* const* w, int D, int H, int num_iter, const uint8_t* sx,
+                        const uint8_t* sz, uint8_t* xh, uint8_t* zh, float* xlog_all, float* zlog_all, size_t iter_stride,
+                        float* llr_out, float* hv, float* hc, float* lx, float* lz)
+{
+    const int n = g->n, mx = g->m[0];
+    const uint8_t* synd[2] = {sx, sz};
+    float* hcn[2] = {hc, hc + (size_t)mx * D};
+    float feat[3 * GB_MAXD + 1], msg[GB_MAXD], acc[2][GB_MAXD];
+    for (int i = 0; i < n * D; ++i) hv[i] = 1.0f;                       /* (:396) */
+    for (int i = 0; i < (g->m[0] + g->m[1]) * D; ++i) hc[i] = 0.0f;     /* (:392-393) */
+    const int rxp = g->m[1] + g->logical[1].rows, rzp = g->m[0] + g->logical[0].rows;
+    for (int it = -1; it < num_iter; ++it) {
+        if (it >= 0) {
+            /* ---- UpdateVNEmbeddings (:714-751): in place, a qubit only reads its own old embedding ---- */
+            for (int v = 0; v < n; ++v) {
+                for (int s = 0; s < 2; ++s) {
+                    const float* const* wm = w + 16 + 4 * s;
+                    const int e0 = g->vptr[s][v], e1 = g->vptr[s][v + 1];
+                    for (int i = 0; i < D; ++i) acc[s][i] = 0.0f;
+                    for (int e = e0; e < e1; ++e) {
+                        const int c = g->vchk[s][e];
+                        for (int i = 0; i < D; ++i) { feat[i] = hcn[s][c * D + i]; feat[D + i] = hv[v * D + i]; } /* (:717-720) */
+                        mlp2(feat, 2 * D, wm[0], wm[1], wm[2], wm[3], H, D, msg);
+                        const float sg = synd[s][c] ? -1.0f : 1.0f;                                       /* (:731-735) */
+                        for (int i = 0; i < D; ++i) { const float mv = msg[i] * sg; acc[s][i] = (e == e0) ? mv : acc[s][i] + mv; }
+                    }
+                    if (e1 > e0) for (int i = 0; i < D; ++i) acc[s][i] = acc[s][i] / (float)(e1 - e0);      /* mean */
+                }
+                for (int i = 0; i < D; ++i) { feat[i] = acc[0][i]; feat[D + i] = acc[1][i]; feat[2 * D + i] = hv[v * D + i]; }
+                mlp2(feat, 3 * D, w[24], w[25], w[26], w[27], H, D, msg);                                   /* (:749) */
+                for (int i = 0; i < D; ++i) hv[v * D + i] = msg[i];
+            }
+            /* ---- cal_logit (:291-314) ---- */
+            for (int v = 0; v < n; ++v) {
+                float L[3];
+                for (int i = 0; i < 3; ++i) {
+                    float a = 0.0f;
+                    for (int k = 0; k < D; ++k) a = FG_FMA(hv[v * D + k], w[28][k * 3 + i], a);
+                    L[i] = a + w[29][i];
+                }
+                llr_out[v] = L[0]; llr_out[n + v] = L[1]; llr_out[2 * n + v] = L[2];
+                lz[v] = fg_softplus(-L[0]) - fg_lse2(-L[2], -L[1]);
+                lx[v] = fg_softplus(-L[2]) - fg_lse2(-L[0], -L[1]);
+            }
+            float* xl = xlog_all ? xlog_all + (size_t)it * iter_stride * rxp : NULL;
+            float* zl = zlog_all ? zlog_all + (size_t)it * iter_stride * rzp : NULL;
+            /* hx_logit / hz_logit feed the next CN update; the full x_perp/z_perp logits are the outputs */
+            for (int c = 0; c < g->m[1]; ++c) {
+                float vq = logit_row_gnn(g->cvn[1] + g->cptr[1][c], g->cptr[1][c + 1] - g->cptr[1][c], lx);
+                if (xl) xl[c] = vq;
+                lz[n + c] = vq; /* stash hz_logit */
+            }
+            for (int c = 0; c < g->m[0]; ++c) {
+                float vq = logit_row_gnn(g->cvn[0] + g->cptr[0][c], g->cptr[0][c + 1] - g->cptr[0][c], lz);
+                if (zl) zl[c] = vq;
+                lx[n + c] = vq; /* stash hx_logit */
+            }
+            if (xl) for (int r = 0; r < g->logical[1].rows; ++r)
+                xl[g->m[1] + r] = logit_row_gnn(g->logical[1].col + g->logical[1].ptr[r], g->logical[1].ptr[r + 1] - g->logical[1].ptr[r], lx);
+            if (zl) for (int r = 0; r < g->logical[0].rows; ++r)
+                zl[g->m[0] + r] = logit_row_gnn(g->logical[0].col + g->logical[0].ptr[r], g->logical[0].ptr[r + 1] - g->logical[0].ptr[r], lz);
+            if (it == num_iter - 1) break;                                                                  /* (:414-415) */
+        }
+        /* ---- UpdateCNEmbeddings (:573-610); before the first iteration with zero logits (:400-401) ---- */
+        for (int s = 0; s < 2; ++s) {
+            const float* const* wm = w + 4 * s;
+            const float* const* we = w + 8 + 4 * s;
+            const float* hlogit = s == 0 ? lx + n : lz + n; /* hx_logit / hz_logit */
+            for (int c = 0; c < g->m[s]; ++c) {
+                const int p0 = g->cptr[s][c], p1 = g->cptr[s][c + 1];
+                float* hto = hcn[s] + (size_t)c * D;
+                for (int i = 0; i < D; ++i) acc[0][i] = 0.0f;
+                for (int j = p0; j < p1; ++j) {
+                    const int v = g->cvn[s][j];
+                    for (int i = 0; i < D; ++i) { feat[i] = hv[v * D + i]; feat[D + i] = hto[i]; }            /* (:577-581) */
+                    mlp2(feat, 2 * D, wm[0], wm[1], wm[2], wm[3], H, D, msg);
+                    for (int i = 0; i < D; ++i) acc[0][i] = (j == p0) ? msg[i] : acc[0][i] + msg[i];
+                }
+                if (p1 > p0) for (int i = 0; i < D; ++i) acc[0][i] = acc[0][i] / (float)(p1 - p0);
+                float lg = 0.0f;
+                if (it >= 0) lg = hlogit[c] * (synd[s][c] ? -1.0f : 1.0f);                                   /* (:417-418) */
+                for (int i = 0; i < D; ++i) { feat[i] = acc[0][i]; feat[D + i] = hto[i]; }
+                feat[2 * D] = lg;                                                                            /* (:607-608) */
+                mlp2(feat, 2 * D + 1, we[0], we[1], we[2], we[3], H, D, msg);
+                for (int i = 0; i < D; ++i) hto[i] = msg[i];
+            }
+        }
+    }
+    for (int v = 0; v < n; ++v) { /* make_hard_decision (:359-367) */
+        float X = llr_out[v], Y = llr_out[n + v], Z = llr_out[2 * n + v];
+        int d = 0;
+        float best = 0.0f;
+        if (X < best) { best = X; d = 1; }
+        if (Z < best) { best = Z; d = 2; }
+        if (Y < best) { best = Y; d = 3; }
+        xh[v] = (uint8_t)(d & 1);
+        zh[v] = (uint8_t)(d >> 1);
+    }
+}
+
+/* synd_x [B,m_x], synd_z [B,m_z]; x_hat/z_hat [B,n]; llr_out [B,3,n] (last iteration's llrx,llry,llrz);
+ * x_logit_all [num_iter,B,m_z+rows(lz)], z_logit_all [num_iter,B,m_x+rows(lx)] (either may be NULL). */
+int og_gnn_bp4(const og_graph* g, const float* const* w, int D, int H, int num_iter, const uint8_t* synd_x,
+               const uint8_t* synd_z, int B, uint8_t* x_hat, uint8_t* z_hat, float* llr_out, float* x_logit_all,
+               float* z_logit_all)
+{
+    if (D > GB_MAXD || num_iter < 1) return -1;
+    const int n = g->n, m = g->m[0] + g->m[1];
+    const int rxp = g->m[1] + g->logical[1].rows, rzp = g->m[0] + g->logical[0].rows;
+#pragma omp parallel
+    {
+        float* hv = (float*)malloc(sizeof(float) * ((size_t)n * D + (size_t)m * D + 2 * ((size_t)n + m) + 4));
+        float* hc = hv + (size_t)n * D;
+        float* lx = hc + (size_t)m * D;
+        float* lz = lx + n + m;
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < B; ++b)
+            gnn_bp4_one(g, w, D, H, num_iter, synd_x + (size_t)b * g->m[0], synd_z + (size_t)b * g->m[1], x_hat + (size_t)b * n,
+                        z_hat + (size_t)b * n, x_logit_all ? x_logit_all + (size_t)b * rxp : NULL,
+                        z_logit_all ? z_logit_all + (size_t)b * rzp : NULL, (size_t)B, llr_out + (size_t)b * 3 * n, hv, hc, lx, lz);
+        free(hv);
     }
     return 0;
 }

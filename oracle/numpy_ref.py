@@ -133,3 +133,80 @@ def feedback_gnn(g, w, llr, logit_hx, logit_hz, synd_x, synd_z):
     z = np.concatenate([out_m[0], out_m[1], h_vn], axis=-1)
     o = (np.tanh(z @ w[10] + w[11]).astype(F) @ w[0] + w[1]).astype(F)  # [B,n,3]
     return np.ascontiguousarray(np.transpose(o, (0, 2, 1)))
+
+
+def gnn_bp4(code, w, synd_x, synd_z, num_iter, D=20):
+    """GNN_BP4.call (sionna/fec/ldpc/gnn.py:383-423) in the reference's own batch-first tensor form, with the two
+    repairs/restatements of oracle/fgnn_oracle.c (4-value cal_logit; message width = num_embed_dims).
+    w = the 30 arrays of the oracle's order.  Returns dict(x_hat [B,n], z_hat, llr [B,3,n], x_logit_all, z_logit_all)."""
+    hx, hz = np.asarray(code.hx), np.asarray(code.hz)
+    B = synd_x.shape[0]
+    n = hx.shape[1]
+    sgx = (F(1) - F(2) * synd_x.astype(F))  # [B,m_x]
+    sgz = (F(1) - F(2) * synd_z.astype(F))
+
+    def mlp(x, ws):
+        return (np.tanh(x @ ws[0] + ws[1]).astype(F) @ ws[2] + ws[3]).astype(F)
+
+    def edges(pcm):
+        c, v = np.nonzero(pcm)  # row-major: check-major, ascending qubit
+        return c, v
+
+    ex, ez = edges(hx), edges(hz)
+
+    def mean_by(msgs, idx, count):  # msgs [B,E,D], aggregate rows with equal idx (ascending edge id inside a group)
+        out = np.zeros((B, count, msgs.shape[-1]), F)
+        order = np.argsort(idx, kind="stable")
+        starts = np.searchsorted(idx[order], np.arange(count))
+        out = np.add.reduceat(msgs[:, order, :], starts, axis=1).astype(F)
+        deg = np.bincount(idx, minlength=count).astype(F)
+        return (out / deg[None, :, None]).astype(F)
+
+    def update_cn(h_vn, hcx, hcz, lgx, lgz):
+        new = []
+        for (c, v), hc, lg, wm, we in ((ex, hcx, lgx, w[0:4], w[8:12]), (ez, hcz, lgz, w[4:8], w[12:16])):
+            m = mean_by(mlp(np.concatenate([h_vn[:, v, :], hc[:, c, :]], -1), wm), c, hc.shape[1])
+            new.append(mlp(np.concatenate([m, hc, lg[:, :, None]], -1), we))
+        return new
+
+    def update_vn(hcx, hcz, h_vn):
+        ms = []
+        for (c, v), hc, sg, wm in ((ex, hcx, sgx, w[16:20]), (ez, hcz, sgz, w[20:24])):
+            msg = mlp(np.concatenate([hc[:, c, :], h_vn[:, v, :]], -1), wm) * sg[:, c, None]
+            ms.append(mean_by(msg.astype(F), v, n))
+        return mlp(np.concatenate([ms[0], ms[1], h_vn], -1), w[24:28])
+
+    def phi_g(x):
+        x = np.clip(x, F(8.5e-8), F(16.635532)).astype(F)
+        return (np.log(np.exp(x) + F(1)) - np.log(np.exp(x) - F(1))).astype(F)
+
+    def rows_logit(mat, llr):  # llr [B,n] -> [B,rows]
+        r, c = np.nonzero(np.asarray(mat))
+        v = llr[:, c]
+        sgn = np.where(v < 0, F(-1), F(1))
+        starts = np.searchsorted(r, np.arange(mat.shape[0]))
+        prod = np.multiply.reduceat(sgn, starts, axis=1)
+        T = np.add.reduceat(phi_g(np.abs(v)), starts, axis=1).astype(F)
+        return (prod * phi_g(T)).astype(F)
+
+    h_vn = np.ones((B, n, D), F)
+    hcx = np.zeros((B, hx.shape[0], D), F)
+    hcz = np.zeros((B, hz.shape[0], D), F)
+    hcx, hcz = update_cn(h_vn, hcx, hcz, np.zeros_like(sgx), np.zeros_like(sgz))
+    xl_all, zl_all = [], []
+    for it in range(num_iter):
+        h_vn = update_vn(hcx, hcz, h_vn)
+        L = (h_vn @ w[28] + w[29]).astype(F)  # [B,n,3]
+        llrx, llry, llrz = L[..., 0], L[..., 1], L[..., 2]
+        llr_z = softplus(-llrx) - lse2(-llrz, -llry)
+        llr_x = softplus(-llrz) - lse2(-llrx, -llry)
+        hz_l, lz_l = rows_logit(hz, llr_x), rows_logit(code.lz, llr_x)
+        hx_l, lx_l = rows_logit(hx, llr_z), rows_logit(code.lx, llr_z)
+        xl_all.append(np.concatenate([hz_l, lz_l], 1))
+        zl_all.append(np.concatenate([hx_l, lx_l], 1))
+        if it == num_iter - 1:
+            break
+        hcx, hcz = update_cn(h_vn, hcx, hcz, hx_l * sgx, hz_l * sgz)
+    dec = np.argmin(np.stack([np.zeros_like(llrx), llrx, llrz, llry], 0), axis=0)
+    return dict(x_hat=(dec & 1).astype(np.uint8), z_hat=(dec >> 1).astype(np.uint8),
+                llr=np.ascontiguousarray(np.stack([llrx, llry, llrz], 1)), x_logit_all=np.stack(xl_all), z_logit_all=np.stack(zl_all))

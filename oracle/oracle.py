@@ -48,6 +48,7 @@ def lib():
         _lib.og_math_apply.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_long]
         _lib.og_num_threads.restype = C.c_int
         _lib.og_philox.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.og_gnn_bp4.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5
     return _lib
 
 
@@ -98,7 +99,8 @@ class OracleGraph:
         self.h = L.og_graph_create(self.n, self.m_x, self.m_z, self.E_x, _p(rx), _p(cx), self.E_z, _p(rz), _p(cz))
         xp, zp = (code.hz, code.hx) if stage_one else (code.hx_perp, code.hz_perp)
         self.rows_xp, self.rows_zp = int(xp.shape[0]), int(zp.shape[0])
-        for which, mat in ((0, xp), (1, zp), (2, code.hx_perp), (3, code.hz_perp)):
+        self.rows_lx, self.rows_lz = int(np.asarray(code.lx).shape[0]), int(np.asarray(code.lz).shape[0])
+        for which, mat in ((0, xp), (1, zp), (2, code.hx_perp), (3, code.hz_perp), (4, code.lx), (5, code.lz)):
             r, c = _coo(mat)
             L.og_graph_set_rows(self.h, which, int(mat.shape[0]), len(r), _p(r), _p(c))
         self.rows_hxp, self.rows_hzp = int(code.hx_perp.shape[0]), int(code.hz_perp.shape[0])
@@ -212,3 +214,20 @@ class OracleGraph:
         if return_llr:
             out["llr"] = llr
         return out
+
+    # -- GNN_BP4.call -------------------------------------------------------------------------------------
+    def gnn_bp4(self, weights, synd_x, synd_z, num_iter, D=20, H=40):
+        w = [np.ascontiguousarray(a, dtype=np.float32) for a in weights]
+        assert len(w) == 30
+        wp = (C.c_void_p * 30)(*[a.ctypes.data for a in w])
+        synd_x = np.ascontiguousarray(synd_x, dtype=np.uint8)
+        synd_z = np.ascontiguousarray(synd_z, dtype=np.uint8)
+        B = synd_x.shape[0]
+        xh = np.empty((B, self.n), np.uint8)
+        zh = np.empty((B, self.n), np.uint8)
+        llr = np.empty((B, 3, self.n), np.float32)
+        xl = np.empty((num_iter, B, self.m_z + self.rows_lz), np.float32)
+        zl = np.empty((num_iter, B, self.m_x + self.rows_lx), np.float32)
+        rc = lib().og_gnn_bp4(self.h, wp, D, H, int(num_iter), _p(synd_x), _p(synd_z), B, _p(xh), _p(zh), _p(llr), _p(xl), _p(zl))
+        assert rc == 0
+        return dict(x_hat=xh, z_hat=zh, llr=llr, x_logit_all=xl, z_logit_all=zl)

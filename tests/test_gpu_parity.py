@@ -7,6 +7,7 @@ tests/test_oracle_kat.py within the north-star tolerance of 1e-4.)
 """
 import numpy as np
 import pytest
+import torch
 
 from helpers import WEIGHTS_882, WEIGHTS_1270, code, gpu_graph, llr_const, oracle_graph, to_gpu
 
@@ -230,3 +231,47 @@ def test_saturation_shortcut_is_exact(name, p):
                              f"llr_ch shortcut={on}")
     finally:
         gg.set_saturation_shortcut(True)
+
+
+def _gnnbp4_weights(seed=11):
+    from feedback_gnn_amd.graph import GNNBP4_SHAPES
+    rng = np.random.RandomState(seed)
+    w = []
+    for shp in GNNBP4_SHAPES:
+        lim = 0.6 if len(shp) == 1 else np.sqrt(6.0 / (shp[0] + shp[1]))
+        w.append(rng.uniform(-lim, lim, size=shp).astype(np.float32))
+    return w
+
+
+@pytest.mark.parametrize("name,B,iters", [("gb48", 21, 5), ("rsurf5", 9, 3), ("ghp882", 6, 4), ("ghp1270", 5, 10)])
+def test_gnn_bp4_bit_exact(name, B, iters):
+    """GNN_BP4 (BASELINE configs[4]) kernel vs the oracle: embeddings-derived LLRs, soft syndromes of every iteration
+    and hard decisions, exactly."""
+    from feedback_gnn_amd.graph import GnnBp4Weights
+    og, gg = oracle_graph(name), gpu_graph(name)
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, 0.05, B)
+    w = _gnnbp4_weights()
+    o = og.gnn_bp4(w, sx, sz, iters)
+    g = gg.gnn_bp4_decode(GnnBp4Weights(w, gg.device), tx, tz, iters)
+    for k in ("llr", "x_logit_all", "z_logit_all", "x_hat", "z_hat"):
+        a, b = o[k], g[k].cpu().numpy()
+        assert np.array_equal(a, b), f"{name} {k}: max|d|={np.abs(a.astype(np.float64) - b).max()}"
+
+
+def test_gnn_bp4_class_contract():
+    import feedback_gnn_amd as F
+    c = code("gb48")
+    dec = F.GNN_BP4(c, num_embed_dims=20, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, num_iter=3, reduce_op="mean",
+                    activation="tanh", use_bias=True)
+    w = _gnnbp4_weights(3)
+    dec.set_weights(w)
+    og = oracle_graph("gb48")
+    ex, ez = og.pauli_noise(SEED, 0.05, 0, 7)
+    sx, sz = og.syndrome(ex, ez)
+    llr_hat, x_hat, z_hat = dec((to_gpu(sx.astype(np.int64)), to_gpu(sz.astype(np.int64))))
+    o = og.gnn_bp4(w, sx, sz, 3)
+    assert len(llr_hat) == 3 and llr_hat[0][0].shape == (og.m_z + og.rows_lz, 7) and x_hat.shape == (c.N, 7)
+    assert np.array_equal(o["x_logit_all"][2].T, llr_hat[2][0].cpu().numpy())
+    assert np.array_equal(o["x_hat"].T, x_hat.cpu().numpy()) and x_hat.dtype == torch.int64
+    with pytest.raises(NotImplementedError):
+        F.GNN_BP4(c, 16, 20, 40, 2, 3, use_bias=True)

@@ -146,3 +146,29 @@ def test_rotated_surface_flagged_vs_bler():
     fl, bl = (flags & 1).mean(), ((flags >> 1) & 1).mean()
     assert abs(fl - 0.2747) < 4 * np.sqrt(0.2747 * 0.7253 / B) * np.sqrt(2), fl
     assert abs(bl - 0.3078) < 4 * np.sqrt(0.3078 * 0.6922 / B) * np.sqrt(2), bl
+
+
+def _gnnbp4_weights(seed=11):
+    from feedback_gnn_amd.graph import GNNBP4_SHAPES
+    rng = np.random.RandomState(seed)
+    w = []
+    for shp in GNNBP4_SHAPES:
+        lim = 0.6 if len(shp) == 1 else np.sqrt(6.0 / (shp[0] + shp[1]))
+        w.append(rng.uniform(-lim, lim, size=shp).astype(np.float32))
+    return w
+
+
+@pytest.mark.parametrize("name", ["gb48", "rsurf5"])
+def test_gnn_bp4_oracle_vs_numpy_restatement(name):
+    """GNN_BP4 (gnn.py:383-423, repaired): C oracle (fmaf chains, polynomial tanh) vs NumPy matmul restatement."""
+    g = oracle_graph(name)
+    ex, ez = g.pauli_noise(SEED, 0.05, 0, 12)
+    sx, sz = g.syndrome(ex, ez)
+    w = _gnnbp4_weights()
+    o = g.gnn_bp4(w, sx, sz, 4)
+    r = R.gnn_bp4(code(name), w, sx, sz, 4)
+    assert np.abs(o["llr"] - r["llr"]).max() <= 2e-4
+    assert np.abs(o["x_logit_all"] - r["x_logit_all"]).max() <= 1e-3 and np.abs(o["z_logit_all"] - r["z_logit_all"]).max() <= 1e-3
+    agree = (o["x_hat"] == r["x_hat"]).mean()
+    assert agree > 0.98  # random weights leave many marginals near ties; exact ties may break either way
+    assert o["x_logit_all"].shape == (4, 12, g.m_z + g.rows_lz)
