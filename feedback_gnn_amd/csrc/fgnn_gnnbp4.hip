@@ -34,6 +34,9 @@ struct GnnBp4Dev {
     MlpDev cn_msg[2], cn_embed[2], vn_msg[2], vn_embed;
     const float* winv;  // [D][4]
     const float* binv;  // [4]
+    // MFMA path: per-lane operand tables, entry e at lane_tab[e*64 + lane]; tab_* = first entry of each MLP
+    const float* lane_tab;
+    int tab_cn_msg[2], tab_cn_embed[2], tab_vn_msg[2], tab_vn_embed, tab_inv;
 };
 
 template <int NIN, int NPAD>
@@ -67,6 +70,61 @@ __device__ __forceinline__ float logit_row_gnn(const float* llr, const int* __re
     }
     const float o = fg_phi_gnn(T);
     return neg ? -o : o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA path (degree-regular graphs).  Same construction as fgnn_gnn.hip: every Dense layer runs transposed on
+// v_mfma_f32_16x16x4_f32 so that a layer's accumulators (column = node on the lane, 4 rows per register) are
+// the next layer's B operand; weight rows are permuted at upload so that k-step s finds units 4s..4s+3 on lane
+// groups 0..3.  A wave owns a tile of 16 receiving nodes.  Per MLP the table holds, in this order:
+//   W1 [3 row tiles][S1 k-steps] | B1 [10] | W2 [2 row tiles][10 k-steps] | B2 [5]
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+template <int S1>
+__device__ __forceinline__ void mlp_tile(const float* __restrict__ lane_tab, int first, const float (&Bin)[S1], float (&out)[5])
+{
+    // Launder the table offset: the operand loads are loop-invariant, and hipcc would otherwise hoist a few hundred
+    // of them out of the tile loops into registers and spill.  (Laundering the integer keeps the pointer's address
+    // space; each operand is then one coalesced 256-byte L1/L2 load right before its MFMA.)
+    int off = first * 64;
+    asm volatile("" : "+v"(off));
+    const float* tab = lane_tab + off;
+    const f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    f4 d[3] = {zero, zero, zero};
+#pragma unroll
+    for (int s = 0; s < S1; ++s)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) d[t] = mfma4(tab[(t * S1 + s) * 64], Bin[s], d[t]);
+    const float* b1 = tab + 3 * S1 * 64;
+    float Hh[10];
+#pragma unroll
+    for (int s = 0; s < 10; ++s) Hh[s] = fg_tanh(d[s >> 2][s & 3] + b1[s * 64]);
+    const float* w2 = b1 + 10 * 64;
+    f4 m0 = zero, m1 = zero;
+#pragma unroll
+    for (int s = 0; s < 10; ++s) {
+        m0 = mfma4(w2[s * 64], Hh[s], m0);
+        m1 = mfma4(w2[(10 + s) * 64], Hh[s], m1);
+    }
+    const float* b2 = w2 + 20 * 64;
+    out[0] = m0[0] + b2[0 * 64];
+    out[1] = m0[1] + b2[1 * 64];
+    out[2] = m0[2] + b2[2 * 64];
+    out[3] = m0[3] + b2[3 * 64];
+    out[4] = m1[0] + b2[4 * 64];
+}
+
+// row of D floats as the 5 B-operand registers of lane group q: element 4s+q for s = 0..4
+__device__ __forceinline__ void load_row5(const float* row, int q, float (&r)[5])
+{
+#pragma unroll
+    for (int s = 0; s < 5; ++s) r[s] = row[4 * s + q];
+}
+__device__ __forceinline__ void store_row5(float* row, int q, const float (&r)[5])
+{
+#pragma unroll
+    for (int s = 0; s < 5; ++s) row[4 * s + q] = r[s];
 }
 
 struct Args {
@@ -218,6 +276,143 @@ __global__ void __launch_bounds__(256) gnn_bp4_kernel(GraphDev g, GnnBp4Dev w, A
     }
 }
 
+template <int DV, int DC>
+__global__ void __launch_bounds__(256, 4) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4Dev w, Args a)
+{
+    extern __shared__ float lds[];
+    const int b = blockIdx.x, tid = threadIdx.x, T = 256;
+    const int n = g.n, mx = g.m_x, mz = g.m_z, m = g.m;
+    float* lx = lds;
+    float* lz = lx + n;
+    float* hlog = lz + n;
+    float* hv = a.work + (size_t)b * (size_t)(n + m) * D;
+    float* hc = hv + (size_t)n * D;
+    const uint8_t* sx = a.synd_x + (size_t)b * mx;
+    const uint8_t* sz = a.synd_z + (size_t)b * mz;
+    const int rxp = mz + g.rows[5], rzp = mx + g.rows[4];
+    for (int i = tid; i < n * D; i += T) hv[i] = 1.0f;
+    for (int i = tid; i < m * D; i += T) hc[i] = 0.0f;
+    for (int c = tid; c < m; c += T) hlog[c] = 0.0f;
+    __syncthreads();
+    float* llr = a.llr_out + (size_t)b * 3 * n;
+    const int l = tid & 63, wave = tid >> 6, j = l & 15, q = l >> 4;
+    const float* tab = w.lane_tab + l;
+    const int vtiles = (n + 15) >> 4, xtiles = (mx + 15) >> 4, ztiles = (mz + 15) >> 4;
+    for (int it = -1; it < a.num_iter; ++it) {
+        if (it >= 0) {
+            // ---- UpdateVNEmbeddings on tiles of 16 qubits ----
+            for (int tile = wave; tile < vtiles; tile += 4) {
+                const int vraw = tile * 16 + j;
+                const bool valid = vraw < n;
+                const int v = valid ? vraw : n - 1;
+                float own[5], Bemb[15];
+                load_row5(hv + (size_t)v * D, q, own);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int ebase = (s2 ? g.E_x : 0) + v * DV;
+                    float acc[5];
+#pragma unroll
+                    for (int k = 0; k < DV; ++k) {
+                        const int c = g.vchk[ebase + k];
+                        float Bin[10], msg[5];
+                        float fr[5];
+                        load_row5(hc + (size_t)((s2 ? mx : 0) + c) * D, q, fr);
+#pragma unroll
+                        for (int s = 0; s < 5; ++s) { Bin[s] = fr[s]; Bin[5 + s] = own[s]; }
+                        mlp_tile<10>(tab, w.tab_vn_msg[s2], Bin, msg);
+                        const float sg = ((s2 ? sz[c] : sx[c]) & 1) ? -1.0f : 1.0f;
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) { const float mv = msg[i] * sg; acc[i] = (k == 0) ? mv : acc[i] + mv; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) Bemb[s2 * 5 + i] = acc[i] / (float)DV;
+                }
+#pragma unroll
+                for (int i = 0; i < 5; ++i) Bemb[10 + i] = own[i];
+                float nh[5];
+                mlp_tile<15>(tab, w.tab_vn_embed, Bemb, nh);
+                // embed_to_llr: L^T = Winv^T nh^T (rows 0..2 land on lane group 0, registers 0..2)
+                const f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                f4 o = zero;
+                int offi = w.tab_inv * 64;
+                asm volatile("" : "+v"(offi));
+                const float* ti = tab + offi;
+#pragma unroll
+                for (int s = 0; s < 5; ++s) o = mfma4(ti[s * 64], nh[s], o);
+                if (valid) {
+                    store_row5(hv + (size_t)v * D, q, nh);
+                    if (q == 0) {
+                        const float L0 = o[0] + ti[5 * 64], L1 = o[1] + ti[6 * 64], L2 = o[2] + ti[7 * 64];
+                        llr[v] = L0;
+                        llr[n + v] = L1;
+                        llr[2 * n + v] = L2;
+                        lz[v] = fg_softplus(-L0) - fg_lse2(-L2, -L1);
+                        lx[v] = fg_softplus(-L2) - fg_lse2(-L0, -L1);
+                    }
+                }
+            }
+            __syncthreads();
+            float* xl = a.xlog_all ? a.xlog_all + ((size_t)it * a.B + b) * rxp : nullptr;
+            float* zl = a.zlog_all ? a.zlog_all + ((size_t)it * a.B + b) * rzp : nullptr;
+            for (int c = tid; c < m; c += T) {
+                const int p0 = g.cptr[c];
+                const float vq = logit_row_gnn(c < mx ? lz : lx, g.cvn + p0, g.cptr[c + 1] - p0);
+                hlog[c] = vq;
+                if (c < mx) { if (zl) zl[c] = vq; }
+                else if (xl) xl[c - mx] = vq;
+            }
+            if (xl)
+                for (int r = tid; r < g.rows[5]; r += T)
+                    xl[mz + r] = logit_row_gnn(lx, g.rcol[5] + g.rptr[5][r], g.rptr[5][r + 1] - g.rptr[5][r]);
+            if (zl)
+                for (int r = tid; r < g.rows[4]; r += T)
+                    zl[mx + r] = logit_row_gnn(lz, g.rcol[4] + g.rptr[4][r], g.rptr[4][r + 1] - g.rptr[4][r]);
+            __syncthreads();
+            if (it == a.num_iter - 1) break;
+        }
+        // ---- UpdateCNEmbeddings: tiles never mix hx and hz checks (the two sides use different weights) ----
+        for (int tile = wave; tile < xtiles + ztiles; tile += 4) {
+            const int s2 = tile >= xtiles;
+            const int local = (s2 ? tile - xtiles : tile) * 16 + j;
+            const int cnt = s2 ? mz : mx;
+            const bool valid = local < cnt;
+            const int c = (s2 ? mx : 0) + (valid ? local : cnt - 1);  // combined check id
+            float own[5], acc[5], Bemb[11];
+            load_row5(hc + (size_t)c * D, q, own);
+#pragma unroll
+            for (int k = 0; k < DC; ++k) {
+                const int v = g.cvn[c * DC + k];
+                float Bin[10], msg[5], fr[5];
+                load_row5(hv + (size_t)v * D, q, fr);
+#pragma unroll
+                for (int s = 0; s < 5; ++s) { Bin[s] = fr[s]; Bin[5 + s] = own[s]; }
+                mlp_tile<10>(tab, w.tab_cn_msg[s2], Bin, msg);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) acc[i] = (k == 0) ? msg[i] : acc[i] + msg[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { Bemb[i] = acc[i] / (float)DC; Bemb[5 + i] = own[i]; }
+            const unsigned sb = (s2 ? sz[c - mx] : sx[c]) & 1;
+            const float lg = (it >= 0) ? hlog[c] * (sb ? -1.0f : 1.0f) : 0.0f;
+            Bemb[10] = (q == 0) ? lg : 0.0f;
+            float nh[5];
+            mlp_tile<11>(tab, w.tab_cn_embed[s2], Bemb, nh);
+            if (valid) store_row5(hc + (size_t)c * D, q, nh);
+        }
+        __syncthreads();
+    }
+    for (int v = tid; v < n; v += T) {
+        const float X = llr[v], Y = llr[n + v], Z = llr[2 * n + v];
+        int d = 0;
+        float best = 0.0f;
+        if (X < best) { best = X; d = 1; }
+        if (Z < best) { best = Z; d = 2; }
+        if (Y < best) { best = Y; d = 3; }
+        a.x_hat[(size_t)b * n + v] = (uint8_t)(d & 1);
+        a.z_hat[(size_t)b * n + v] = (uint8_t)(d >> 1);
+    }
+}
+
 }  // namespace
 
 struct fgnn_gnnbp4_weights {
@@ -260,6 +455,55 @@ extern "C" int fgnn_gnnbp4_weights_create(const float* const host_arrays[30], in
     for (int k = 0; k < D; ++k)
         for (int i = 0; i < 3; ++i) h[owi + k * 4 + i] = host_arrays[28][k * 3 + i];
     std::memcpy(&h[obi], host_arrays[29], 3 * sizeof(float));
+    // per-lane MFMA operand tables
+    std::vector<float> T;
+    int tab_start[7], tab_inv;
+    auto entry = [&]() { size_t e = T.size() / 64; T.resize(T.size() + 64, 0.0f); return e; };
+    for (int qm = 0; qm < 7; ++qm) {
+        const float* const* a = host_arrays + 4 * qm;
+        const int S1 = (nin[qm] + 3) / 4;
+        tab_start[qm] = (int)(T.size() / 64);
+        for (int t = 0; t < 3; ++t)
+            for (int st = 0; st < S1; ++st) {
+                size_t e = entry();
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int rho = lane & 15, kk = lane >> 4, unit = 16 * t + 4 * (rho & 3) + (rho >> 2), k = 4 * st + kk;
+                    T[e * 64 + lane] = (unit < H && k < nin[qm]) ? a[0][(size_t)k * H + unit] : 0.0f;
+                }
+            }
+        for (int st = 0; st < 10; ++st) {
+            size_t e = entry();
+            for (int lane = 0; lane < 64; ++lane) T[e * 64 + lane] = a[1][4 * st + (lane >> 4)];
+        }
+        for (int u = 0; u < 2; ++u)
+            for (int st = 0; st < 10; ++st) {
+                size_t e = entry();
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int rho = lane & 15, kk = lane >> 4, rp = rho & 3, qp = rho >> 2;
+                    const int mu = (u == 0) ? 4 * rp + qp : (rp == 0 ? 16 + qp : -1);
+                    T[e * 64 + lane] = mu >= 0 ? a[2][(size_t)(4 * st + kk) * D + mu] : 0.0f;
+                }
+            }
+        for (int i = 0; i < 5; ++i) {
+            size_t e = entry();
+            for (int lane = 0; lane < 64; ++lane) T[e * 64 + lane] = a[3][i < 4 ? 4 * i + (lane >> 4) : 16 + (lane >> 4)];
+        }
+    }
+    tab_inv = (int)(T.size() / 64);
+    for (int st = 0; st < 5; ++st) {
+        size_t e = entry();
+        for (int lane = 0; lane < 64; ++lane) {
+            const int rho = lane & 15, kk = lane >> 4;
+            T[e * 64 + lane] = rho < 3 ? host_arrays[28][(size_t)(4 * st + kk) * 3 + rho] : 0.0f;
+        }
+    }
+    for (int r = 0; r < 3; ++r) {
+        size_t e = entry();
+        for (int lane = 0; lane < 64; ++lane) T[e * 64 + lane] = host_arrays[29][r];
+    }
+    const size_t otab = push(T.size());
+    std::memcpy(&h[otab], T.data(), T.size() * sizeof(float));
+
     fgnn_gnnbp4_weights* w = new fgnn_gnnbp4_weights();
     w->device = device;
     w->blob = nullptr;
@@ -281,6 +525,15 @@ extern "C" int fgnn_gnnbp4_weights_create(const float* const host_arrays[30], in
     }
     w->d.winv = base + owi;
     w->d.binv = base + obi;
+    w->d.lane_tab = base + otab;
+    w->d.tab_cn_msg[0] = tab_start[0];
+    w->d.tab_cn_msg[1] = tab_start[1];
+    w->d.tab_cn_embed[0] = tab_start[2];
+    w->d.tab_cn_embed[1] = tab_start[3];
+    w->d.tab_vn_msg[0] = tab_start[4];
+    w->d.tab_vn_msg[1] = tab_start[5];
+    w->d.tab_vn_embed = tab_start[6];
+    w->d.tab_inv = tab_inv;
     *out = w;
     return FGNN_OK;
 }
@@ -323,6 +576,11 @@ extern "C" int fgnn_gnnbp4_decode(const fgnn_graph* g, const fgnn_gnnbp4_weights
     a.zlog_all = z_logit_all;
     a.work = static_cast<float*>(workspace);
     const size_t lds_bytes = (size_t)(2 * g->d.n + g->d.m) * sizeof(float);
+    if (g->d.dvx == 3 && g->d.dvz == 3 && g->d.dc == 6 && !g->force_generic) {
+        hipLaunchKernelGGL((gnn_bp4_mfma_kernel<3, 6>), dim3(B), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), g->d, w->d, a);
+        FGNN_HIP_CHECK(hipGetLastError());
+        return FGNN_OK;
+    }
     hipLaunchKernelGGL(gnn_bp4_kernel, dim3(B), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), g->d, w->d, a);
     FGNN_HIP_CHECK(hipGetLastError());
     return FGNN_OK;

@@ -275,3 +275,22 @@ def test_gnn_bp4_class_contract():
     assert np.array_equal(o["x_hat"].T, x_hat.cpu().numpy()) and x_hat.dtype == torch.int64
     with pytest.raises(NotImplementedError):
         F.GNN_BP4(c, 16, 20, 40, 2, 3, use_bias=True)
+
+
+def test_gnn_bp4_mfma_and_valu_kernels_agree():
+    from feedback_gnn_amd.graph import GnnBp4Weights
+    name, B, iters = "ghp882", 5, 3
+    og, gg = oracle_graph(name), gpu_graph(name)
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, 0.05, B, first=9)
+    w = _gnnbp4_weights(21)
+    o = og.gnn_bp4(w, sx, sz, iters)
+    gw = GnnBp4Weights(w, gg.device)
+    a = gg.gnn_bp4_decode(gw, tx, tz, iters)
+    gg.force_generic(True)
+    try:
+        b = gg.gnn_bp4_decode(gw, tx, tz, iters)
+    finally:
+        gg.force_generic(False)
+    for k in ("llr", "x_logit_all", "z_logit_all", "x_hat", "z_hat"):
+        assert np.array_equal(o[k], b[k].cpu().numpy()), f"VALU {k}"
+        assert np.array_equal(o[k], a[k].cpu().numpy()), f"MFMA {k}: {np.abs(o[k].astype(np.float64) - a[k].cpu().numpy()).max()}"
