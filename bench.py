@@ -64,12 +64,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; FGNN_BENCH_BACKEND=gloo (self-test of the multi-process flow on a 1-GPU box) lets several
+    # ranks share a device and reduces through host memory
+    backend = os.environ.get("FGNN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def allreduce(t, op):
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+            return t
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        return c.to(t.device)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -125,10 +140,9 @@ def main():
     launches = g.profile_read()
     g.profile_enable(0)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = allreduce(torch.tensor([elapsed], dtype=torch.float64, device="cuda"), dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        counts = allreduce(counts, dist.ReduceOp.SUM)
     cnt = counts.cpu().numpy()
     total_cw = world * B * K
     value = total_cw / elapsed
