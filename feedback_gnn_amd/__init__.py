@@ -23,6 +23,9 @@ def __getattr__(name):
     if name in ("sim_ber", "count_block_errors", "PlotBER"):
         from . import utils as _u
         return getattr(_u, name)
+    if name in ("LDPCBPDecoder", "BP_BSC_Model"):
+        from . import decoding as _d
+        return getattr(_d, name)
     if name == "GNN_BP4":
         from .gnn import GNN_BP4
         return GNN_BP4

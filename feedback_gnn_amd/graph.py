@@ -279,6 +279,28 @@ class TannerGraph:
             out["rounds"] = rounds
         return out
 
+    # ---- binary syndrome BP on the hx graph (LDPCBPDecoder, is_syndrome=True) ----------------------------------
+    def bp2_decode(self, synd, num_iter, cn_type="boxplus-phi", factor=1.0, llr_ch=None, llr_const=0.0, B=None, want_soft=True,
+                   want_hard=True):
+        if cn_type not in CN_TYPES:
+            raise ValueError("Unknown node type.")
+        if synd is not None:
+            B = int(synd.shape[0])
+            synd = self._chk(synd, (B, self.m_x), torch.uint8, "syndrome")
+        if llr_ch is not None:
+            B = int(llr_ch.shape[0]) if B is None else B
+            llr_ch = self._chk(llr_ch, (B, self.n), torch.float32, "llr_ch")
+        soft = self._new((B, self.n), torch.float32) if want_soft else None
+        hard = self._new((B, self.n), torch.uint8) if want_hard else None
+        check(_lib.lib().fgnn_bp2_decode(self.handle, CN_TYPES[cn_type], int(num_iter), float(factor), _ptr(llr_ch), float(llr_const),
+                                         _ptr(synd), B, _ptr(soft), _ptr(hard), _stream(self.device)))
+        return soft, hard
+
+    def bsc_noise(self, seed, p, first_sample, B):
+        e = self._new((B, self.n), torch.uint8)
+        check(_lib.lib().fgnn_bsc_noise(int(seed), float(np.float32(p)), int(first_sample), B, self.n, _ptr(e), _stream(self.device)))
+        return e
+
     # ---- GNN_BP4 -----------------------------------------------------------------------------------------
     def gnn_bp4_decode(self, weights, synd_x, synd_z, num_iter, return_logits=True, workspace=None):
         B = int(synd_x.shape[0])

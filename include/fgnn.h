@@ -143,6 +143,15 @@ int fgnn_sandwich_decode(const fgnn_graph* g, int num_layers, const int32_t* ite
                          uint8_t* z_hat, float* llr_final, uint8_t* rounds, void* workspace, size_t ws_bytes,
                          void* stream);
 
+/* Binary syndrome BP — LDPCBPDecoder.call with is_syndrome=True, sionna/fec/ldpc/decoding.py:874-1048 (SURVEY.md §8f
+ * rank 1).  The parity-check matrix is side 0 (hx) of the graph.  llr_ch [B,n] are LOGITS as in the reference (clipped
+ * to +-20, sign flipped on entry and exit, :918-920,:940,:1031) or NULL (= llr_const everywhere); synd [B,m_x] or NULL
+ * (all-zero syndrome = ordinary decoding).  soft_out [B,n] = output logits, hard_out [B,n] = (0 < logit) (:1033-1034). */
+int fgnn_bp2_decode(const fgnn_graph* g, int cn_type, int num_iter, float normalization_factor, const float* llr_ch,
+                    float llr_const, const uint8_t* synd, int B, float* soft_out, uint8_t* hard_out, void* stream);
+/* BinarySymmetricChannel on the all-zero word, BP_BSC_Model.call feedback_gnn.py:213-214: noise = u < p (Philox stream). */
+int fgnn_bsc_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, uint8_t* noise, void* stream);
+
 /* GNN_BP4 (the syndrome-only "full GNN" decoder), sionna/fec/ldpc/gnn.py:71-423 with UpdateCNEmbeddings (:426-610)
  * and UpdateVNEmbeddings (:612-751): num_mlp_layers=2, tanh, mean, use_bias, num_embed_dims=20, num_hidden_units=40.
  * Weights: 30 host arrays — cn_msg_x, cn_msg_z, cn_embed_x, cn_embed_z, vn_msg_x, vn_msg_z, vn_embed, each

@@ -784,6 +784,90 @@ int og_gnn_bp4(const og_graph* g, const float* const* w, int D, int H, int num_i
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Binary syndrome BP: LDPCBPDecoder.call with is_syndrome=True, sionna/fec/ldpc/decoding.py:874-1048
+ * (fork additions: syndrome sign :905-908, :595/:658/:767, normalization_factor :991).  Uses side 0 (hx) of
+ * the graph as the parity-check matrix.  llr_ch are LOGITS (sign flipped on entry :940 and on exit :1031),
+ * clipped to +-20 (:918-920).  Its phi is log(exp(x)+1) - log(exp(x)-1) (:632-633), not the softplus form.
+ * soft_out [B,n] = output logits, hard_out [B,n] = (0 < logit) (:1033-1034); either may be NULL.
+ * ------------------------------------------------------------------------------------------ */
+static void cn_phi_log(const int* slot, int deg, float* msg, int synd, float factor, float* tmp)
+{
+    int neg = synd;
+    float T = 0.0f;
+    for (int j = 0; j < deg; ++j) {
+        float v = msg[slot[j]];
+        neg ^= (v < 0.0f);
+        float a = fg_phi_gnn(FG_ABS(v));
+        tmp[j] = a;
+        T = T + a;
+    }
+    for (int j = 0; j < deg; ++j) {
+        float v = msg[slot[j]];
+        float out = fg_phi_gnn(T - tmp[j]);
+        int sg = neg ^ (v < 0.0f);
+        out = sg ? -out : out;
+        msg[slot[j]] = out * factor;
+    }
+}
+
+int og_bp2_decode(const og_graph* g, int cn_type, int num_iter, float factor, const float* llr_ch, float llr_const,
+                  const uint8_t* synd, int B, float* soft_out, uint8_t* hard_out)
+{
+    const int n = g->n, m = g->m[0];
+#pragma omp parallel
+    {
+        og_scratch sc;
+        scratch_alloc(g, &sc);
+        float* msg = sc.msg[0];
+#pragma omp for schedule(dynamic, 4)
+        for (int b = 0; b < B; ++b) {
+            memset(msg, 0, sizeof(float) * (size_t)g->E[0]);
+            for (int it = 0; it <= num_iter; ++it) {
+                for (int v = 0; v < n; ++v) {
+                    float lc = llr_ch ? llr_ch[(size_t)b * n + v] : llr_const;
+                    lc = FG_MIN(FG_MAX(lc, -20.0f), 20.0f); /* (:918-920) */
+                    const float L = -1.0f * lc;              /* (:940) */
+                    float S = 0.0f;
+                    for (int e = g->vptr[0][v]; e < g->vptr[0][v + 1]; ++e) S = S + msg[e];
+                    if (it == num_iter) {
+                        const float o = -1.0f * (L + S);     /* (:1025,:1031) */
+                        if (soft_out) soft_out[(size_t)b * n + v] = o;
+                        if (hard_out) hard_out[(size_t)b * n + v] = (uint8_t)(0.0f < o);
+                        continue;
+                    }
+                    const float x = S + L;                    /* _vn_update (:520-521) */
+                    for (int e = g->vptr[0][v]; e < g->vptr[0][v + 1]; ++e) msg[e] = x - msg[e];
+                }
+                if (it == num_iter) break;
+                for (int c = 0; c < m; ++c) {
+                    const int* slot = g->cslot[0] + g->cptr[0][c];
+                    const int deg = g->cptr[0][c + 1] - g->cptr[0][c];
+                    const int sy = synd ? (synd[(size_t)b * m + c] & 1) : 0;
+                    if (cn_type == OG_CN_PHI) cn_phi_log(slot, deg, msg, sy, factor, sc.tmp);
+                    else if (cn_type == OG_CN_MINSUM) cn_minsum(slot, deg, msg, sy, factor, sc.tmp);
+                    else cn_tanh(slot, deg, msg, sy, factor, sc.tmp);
+                }
+            }
+        }
+        scratch_free(&sc);
+    }
+    return 0;
+}
+
+/* BinarySymmetricChannel on the all-zero word (feedback_gnn.py:213-214): noise = u < p, same Philox stream. */
+int og_bsc_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, uint8_t* noise)
+{
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int q0 = 0; q0 < n; q0 += 4) {
+            float u[4];
+            fg_uniform4(seed, first_sample + (uint64_t)b, (uint32_t)(q0 >> 2), u);
+            for (int k = 0; k < 4 && q0 + k < n; ++k) noise[(size_t)b * n + q0 + k] = (uint8_t)(u[k] < p);
+        }
+    return 0;
+}
+
 /* elementwise wrappers so tests can probe the shared math from Python */
 void og_math_apply(int fn, const float* x, float* y, long nelem)
 {

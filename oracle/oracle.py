@@ -48,6 +48,8 @@ def lib():
         _lib.og_math_apply.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_long]
         _lib.og_num_threads.restype = C.c_int
         _lib.og_philox.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.og_bp2_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.og_bsc_noise.argtypes = [C.c_uint64, C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
         _lib.og_gnn_bp4.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5
     return _lib
 
@@ -231,3 +233,21 @@ class OracleGraph:
         rc = lib().og_gnn_bp4(self.h, wp, D, H, int(num_iter), _p(synd_x), _p(synd_z), B, _p(xh), _p(zh), _p(llr), _p(xl), _p(zl))
         assert rc == 0
         return dict(x_hat=xh, z_hat=zh, llr=llr, x_logit_all=xl, z_logit_all=zl)
+
+    # -- binary syndrome BP (LDPCBPDecoder, is_syndrome=True) on the hx graph ---------------------------------
+    def bp2_decode(self, synd, num_iter, cn_type="boxplus-phi", factor=1.0, llr_ch=None, llr_const=0.0):
+        B = synd.shape[0]
+        synd = np.ascontiguousarray(synd, dtype=np.uint8)
+        if llr_ch is not None:
+            llr_ch = np.ascontiguousarray(llr_ch, dtype=np.float32)
+        soft = np.empty((B, self.n), np.float32)
+        hard = np.empty((B, self.n), np.uint8)
+        rc = lib().og_bp2_decode(self.h, CN_TYPES[cn_type], int(num_iter), float(factor), _p(llr_ch), float(llr_const), _p(synd), B,
+                                 _p(soft), _p(hard))
+        assert rc == 0
+        return soft, hard
+
+    def bsc_noise(self, seed, p, first_sample, B):
+        e = np.empty((B, self.n), np.uint8)
+        lib().og_bsc_noise(int(seed), float(np.float32(p)), int(first_sample), B, self.n, _p(e))
+        return e

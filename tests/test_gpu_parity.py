@@ -294,3 +294,46 @@ def test_gnn_bp4_mfma_and_valu_kernels_agree():
     for k in ("llr", "x_logit_all", "z_logit_all", "x_hat", "z_hat"):
         assert np.array_equal(o[k], b[k].cpu().numpy()), f"VALU {k}"
         assert np.array_equal(o[k], a[k].cpu().numpy()), f"MFMA {k}: {np.abs(o[k].astype(np.float64) - a[k].cpu().numpy()).max()}"
+
+
+@pytest.mark.parametrize("name", ["ghp882", "gb48", "rsurf5"])
+@pytest.mark.parametrize("cn_type,factor", [("boxplus-phi", 1.0), ("minsum", 0.8), ("boxplus", 0.625)])
+def test_binary_syndrome_bp_bit_exact(name, cn_type, factor):
+    """LDPCBPDecoder(is_syndrome=True) on hx (decoding.py:874-1048) — kernel vs oracle, soft logits and hard decisions."""
+    B = 37
+    og, gg = oracle_graph(name), gpu_graph(name)
+    e = og.bsc_noise(SEED, 0.04, 0, B)
+    ge = gg.bsc_noise(SEED, 0.04, 0, B)
+    assert np.array_equal(e, ge.cpu().numpy())
+    synd = (e.astype(np.int64) @ code(name).hx.T % 2).astype(np.uint8)
+    L = float(-np.log((np.float32(1) - np.float32(0.2)) / np.float32(0.2), dtype=np.float32))
+    s0, h0 = og.bp2_decode(synd, 24, cn_type, factor, llr_const=L)
+    s1, h1 = gg.bp2_decode(to_gpu(synd), 24, cn_type, factor, llr_const=L)
+    assert np.array_equal(s0, s1.cpu().numpy()) and np.array_equal(h0, h1.cpu().numpy())
+    llr = np.random.RandomState(2).uniform(-25, 3, size=(B, og.n)).astype(np.float32)  # exercises the +-20 clip
+    s0, h0 = og.bp2_decode(synd, 7, cn_type, factor, llr_ch=llr)
+    s1, h1 = gg.bp2_decode(to_gpu(synd), 7, cn_type, factor, llr_ch=to_gpu(llr))
+    assert np.array_equal(s0, s1.cpu().numpy()) and np.array_equal(h0, h1.cpu().numpy())
+
+
+def test_bp_bsc_model_contract_and_published_band():
+    """examples/QLDPC.ipynb cell 7: binary BP-64 on hx of [[882,24]] over a BSC, p0=0.2, logical_pcm=hz_perp;
+    row p=0.047 -> 798/10000 flagged = BLER (binomial band, independent draw)."""
+    import feedback_gnn_amd as F
+    c = code("ghp882")
+    dec = F.LDPCBPDecoder(c.hx, is_syndrome=True, num_iter=64)
+    model = F.BP_BSC_Model(pcm=c.hx, decoder=dec, logical_pcm=c.hz_perp, p0=0.2)
+    p = 0.07 * 2 / 3
+    s_hat, ls_hat = model(10000, p)
+    assert s_hat.shape == (10000, 441) and ls_hat.shape == (10000, 453)
+    fl, bl = float(s_hat.any(1).float().mean()), float(ls_hat.any(1).float().mean())
+    assert abs(bl - 0.0798) < 4 * np.sqrt(0.0798 * 0.92 / 10000) * np.sqrt(2), bl
+    assert fl <= bl + 1e-9
+    noise, noise_hat = F.BP_BSC_Model(pcm=c.hx, decoder=dec, p0=0.2)(64, 0.02)
+    assert noise.shape == (64, 882) and noise_hat.shape == (64, 882)
+    # decoder layer contract: (llr[bs,n] logits, syndrome[m,bs]) -> hard decisions
+    e = noise.to(torch.uint8)
+    synd = torch.from_numpy((e.cpu().numpy().astype(np.int64) @ c.hx.T % 2)).cuda()
+    llr = torch.full((64, 882), float(-np.log(0.8 / 0.2)), dtype=torch.float32, device="cuda")
+    out = dec((llr, synd.t()))
+    assert torch.equal(out, noise_hat)
