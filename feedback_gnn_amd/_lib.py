@@ -61,6 +61,10 @@ _SIGNATURES = {
     "fgnn_bp2_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "fgnn_bsc_noise": (C.c_int, [C.c_uint64, C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "fgnn_residual_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4),
+    "fgnn_graph_set_basis": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "fgnn_osd0": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "fgnn_compact": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fgnn_gnnbp4_weights_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "fgnn_gnnbp4_weights_destroy": (None, [C.c_void_p]),
     "fgnn_gnnbp4_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),

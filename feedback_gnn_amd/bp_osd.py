@@ -1,0 +1,59 @@
+"""OSD-0 post-processing and the BP4+OSD evaluation model on MI355X — SURVEY.md §8(f) rank 2.
+
+Drop-ins for `OSD0_Decoder` and `BP4_OSD_Model` of /root/reference sionna/fec/ldpc/bp_osd.py:8-191.
+"""
+import numpy as np
+import torch
+
+from ._lib import ROWS_LX, ROWS_LZ
+from .feedback_gnn import Pauli
+
+
+class OSD0_Decoder:
+    """Order-0 ordered-statistics decoder (bp_osd.py:8-77).  The reference's `call(llr, pcm, s, bs)` takes the row
+    basis as a dense batched tensor; here the basis lives in the device graph (`fgnn_graph_set_basis`) and the
+    decoder is driven by `BP4_OSD_Model`."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+
+class BP4_OSD_Model:
+    """``BP4_OSD_Model(code, bp4_decoder, osd_decoder)``; ``model(batch_size, p)`` → ``(zeros_like(ls_hat), ls_hat)`` with
+    ``ls_hat[bs, rows(lz)+rows(lx)] = [lz·x_diff ; lx·z_diff]`` (bp_osd.py:159-191).  BP4 runs on every sample with
+    ``llr = log(3(1-p)/p)`` (:106); the samples whose estimate misses the syndrome get both halves re-solved by OSD-0 from
+    the binary reliabilities of their BP marginals (:117-131, :138-157)."""
+
+    def __init__(self, code, bp4_decoder, osd_decoder, *, seed=0x5EED, rank=0, world_size=1):
+        self.code, self.bp4_decoder, self.osd_decoder = code, bp4_decoder, osd_decoder
+        self.graph = bp4_decoder.graph
+        self.graph.set_basis(0, code.pivot_hx)
+        self.graph.set_basis(1, code.pivot_hz)
+        self.channel = Pauli(self.graph, seed=seed)
+        self.rank, self.world_size, self._next = int(rank), int(world_size), 0
+        self.last_num_osd = 0
+
+    def decode(self, batch_size, p):
+        B, g, d = int(batch_size), self.graph, self.bp4_decoder
+        first = self._next + self.rank * B
+        self._next += self.world_size * B
+        ex, ez = self.channel(B, float(p), first)
+        sx, sz = g.syndrome(ex, ez)
+        pf = np.float32(p)
+        L = float(np.log(np.float32(3.0) * (np.float32(1.0) - pf) / pf, dtype=np.float32))
+        out = g.bp4_decode(sx, sz, d.num_iter, d.cn_type, d.normalization_factor, llr_const=L, want_logits=False)
+        x_hat, z_hat = out["x_hat"], out["z_hat"]
+        _, _, flags = g.residual(ex, ez, x_hat, z_hat, want_arrays=False)  # bit 0 = syndrome missed = `err` (:117-120)
+        index, nact = g.compact(flags, 1)
+        self.last_num_osd = nact
+        if nact:
+            g.osd0(0, sx, z_hat, marg=out["llr"], index=index, nact=nact)  # z_hat_osd from hx, osd_llrz (:155)
+            g.osd0(1, sz, x_hat, marg=out["llr"], index=index, nact=nact)  # x_hat_osd from hz, osd_llrx (:156)
+        return dict(noise_x=ex, noise_z=ez, x_hat=x_hat, z_hat=z_hat)
+
+    def __call__(self, batch_size, ebno_db=None, **kw):
+        o = self.decode(batch_size, kw.get("p", ebno_db))
+        ls_hat, _ = self.graph.residual_rows(ROWS_LZ, ROWS_LX, o["noise_x"], o["noise_z"], o["x_hat"], o["z_hat"])
+        return torch.zeros_like(ls_hat), ls_hat
+
+    call = __call__

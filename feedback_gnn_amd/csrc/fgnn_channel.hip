@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) merge_kernel(const uint8_t* __restrict__ 
 }
 
 // residual check (feedback_gnn.py:343-361) + row-wise any() (metrics.py:221-223)
-__global__ void __launch_bounds__(1024) residual_kernel(GraphDev g, int B, int tpc, int cpb, const uint8_t* __restrict__ ex,
+__global__ void __launch_bounds__(1024) residual_kernel(GraphDev g, int RX, int RZ, int B, int tpc, int cpb, const uint8_t* __restrict__ ex,
                                                         const uint8_t* __restrict__ ez, const uint8_t* __restrict__ xh,
                                                         const uint8_t* __restrict__ zh, uint8_t* __restrict__ s_hat,
                                                         uint8_t* __restrict__ ls_hat, uint8_t* __restrict__ flags)
@@ -141,11 +141,12 @@ __global__ void __launch_bounds__(1024) residual_kernel(GraphDev g, int B, int t
             mine |= bit;
         }
         // ls_hat = [hx_perp xd ; hz_perp zd]  (:352-353,:356)
-        const int r0 = g.rows[FGNN_ROWS_HX_PERP], r1 = g.rows[FGNN_ROWS_HZ_PERP];
+        // RX / RZ = the row sets applied to xd / zd: (hx_perp, hz_perp) for the sandwich model, (lz, lx) for BP4_OSD_Model
+        const int r0 = g.rows[RX], r1 = g.rows[RZ];
         for (int r = lane; r < r0 + r1; r += tpc) {
             unsigned bit;
-            if (r < r0) bit = row_parity(xd, g.rcol[FGNN_ROWS_HX_PERP], g.rptr[FGNN_ROWS_HX_PERP][r], g.rptr[FGNN_ROWS_HX_PERP][r + 1]);
-            else bit = row_parity(zd, g.rcol[FGNN_ROWS_HZ_PERP], g.rptr[FGNN_ROWS_HZ_PERP][r - r0], g.rptr[FGNN_ROWS_HZ_PERP][r - r0 + 1]);
+            if (r < r0) bit = row_parity(xd, g.rcol[RX], g.rptr[RX][r], g.rptr[RX][r + 1]);
+            else bit = row_parity(zd, g.rcol[RZ], g.rptr[RZ][r - r0], g.rptr[RZ][r - r0 + 1]);
             if (ls_hat) ls_hat[(size_t)b * (r0 + r1) + r] = (uint8_t)bit;
             mine |= bit << 1;
         }
@@ -230,20 +231,27 @@ extern "C" int fgnn_merge(const uint8_t* errors, const uint8_t* x_upd, const uin
     return FGNN_OK;
 }
 
-extern "C" int fgnn_residual(const fgnn_graph* g, const uint8_t* noise_x, const uint8_t* noise_z, const uint8_t* x_hat,
-                             const uint8_t* z_hat, int B, uint8_t* s_hat, uint8_t* ls_hat, uint8_t* flags, void* stream)
+extern "C" int fgnn_residual_rows(const fgnn_graph* g, int rows_x, int rows_z, const uint8_t* noise_x, const uint8_t* noise_z,
+                                  const uint8_t* x_hat, const uint8_t* z_hat, int B, uint8_t* s_hat, uint8_t* ls_hat, uint8_t* flags,
+                                  void* stream)
 {
     if (!g || !noise_x || !noise_z || !x_hat || !z_hat || B < 0) return fgnn_fail(FGNN_ERR_ARG, "bad residual arguments");
-    if (!g->d.rptr[FGNN_ROWS_HX_PERP] || !g->d.rptr[FGNN_ROWS_HZ_PERP])
-        return fgnn_fail(FGNN_ERR_STATE, "hx_perp / hz_perp row sets not installed (fgnn_graph_set_rows)");
+    if (rows_x < 0 || rows_x > 5 || rows_z < 0 || rows_z > 5 || !g->d.rptr[rows_x] || !g->d.rptr[rows_z])
+        return fgnn_fail(FGNN_ERR_STATE, "row sets for the residual check not installed (fgnn_graph_set_rows)");
     if (B == 0) return FGNN_OK;
     FGNN_HIP_CHECK(hipSetDevice(g->device));
     LaunchGeom L = fgnn_geom(g, B);
     size_t lds = ((L.cpb * sizeof(unsigned) + 15) & ~size_t(15)) + (size_t)L.cpb * 2 * g->d.n;
-    hipLaunchKernelGGL(residual_kernel, dim3(L.blocks), dim3(L.threads), lds, static_cast<hipStream_t>(stream), g->d, B, L.tpc,
-                       L.cpb, noise_x, noise_z, x_hat, z_hat, s_hat, ls_hat, flags);
+    hipLaunchKernelGGL(residual_kernel, dim3(L.blocks), dim3(L.threads), lds, static_cast<hipStream_t>(stream), g->d, rows_x, rows_z, B,
+                       L.tpc, L.cpb, noise_x, noise_z, x_hat, z_hat, s_hat, ls_hat, flags);
     FGNN_HIP_CHECK(hipGetLastError());
     return FGNN_OK;
+}
+
+extern "C" int fgnn_residual(const fgnn_graph* g, const uint8_t* noise_x, const uint8_t* noise_z, const uint8_t* x_hat,
+                             const uint8_t* z_hat, int B, uint8_t* s_hat, uint8_t* ls_hat, uint8_t* flags, void* stream)
+{
+    return fgnn_residual_rows(g, FGNN_ROWS_HX_PERP, FGNN_ROWS_HZ_PERP, noise_x, noise_z, x_hat, z_hat, B, s_hat, ls_hat, flags, stream);
 }
 
 extern "C" int fgnn_count_flags(const uint8_t* flags, int B, uint64_t* counts, void* stream)

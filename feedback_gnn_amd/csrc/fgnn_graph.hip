@@ -187,6 +187,8 @@ extern "C" void fgnn_graph_destroy(fgnn_graph* g)
     if (!g) return;
     (void)hipSetDevice(g->device);
     for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
+    for (void* p : g->basis_dev)
+        if (p) (void)hipFree(p);
     for (void* p : g->allocs) (void)hipFree(p);
     for (auto& r : g->row_alloc)
         for (void* p : r)

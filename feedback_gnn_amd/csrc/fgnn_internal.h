@@ -38,6 +38,8 @@ struct fgnn_graph {
     // host copies of the canonical edge lists (fgnn_graph_edges)
     std::vector<int32_t> h_chk[2], h_var[2];
     void* row_alloc[6][2];
+    void* basis_dev[2] = {nullptr, nullptr};  // pivot rows of hx / hz (fgnn_graph_set_basis, OSD)
+    int basis_rank[2] = {0, 0};
     // optional per-launch timing of the BP4 kernel with HIP events on the launch stream (fgnn_profile_*)
     mutable bool prof_on = false;
     mutable int prof_n = 0;

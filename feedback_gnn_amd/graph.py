@@ -279,6 +279,39 @@ class TannerGraph:
             out["rounds"] = rounds
         return out
 
+    # ---- OSD-0 (bp_osd.py) -----------------------------------------------------------------------------------------
+    def set_basis(self, side, pivot_rows):
+        piv = np.ascontiguousarray(pivot_rows, dtype=np.int32)
+        check(_lib.lib().fgnn_graph_set_basis(self.handle, int(side), len(piv), _np_ptr(piv)))
+
+    def compact(self, mask, bit=1):
+        """Device index list of the samples with (mask & bit) != 0 and their count (one 4-byte device->host read)."""
+        B = int(mask.shape[0])
+        index = self._new((max(B, 1),), torch.int32)
+        count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        check(_lib.lib().fgnn_compact(_ptr(mask), int(bit), B, _ptr(index), _ptr(count), _stream(self.device)))
+        return index, int(count.item())
+
+    def osd0(self, side, synd, e_hat, marg=None, llr_bin=None, index=None, nact=0):
+        """Overwrite e_hat[b] (uint8 [B,n]) for the listed samples with the OSD-0 solution of side 0 (hx) / 1 (hz)."""
+        B = int(synd.shape[0])
+        synd = self._chk(synd, (B, self.m_x if side == 0 else self.m_z), torch.uint8, "synd")
+        self._chk(e_hat, (B, self.n), torch.uint8, "e_hat")
+        check(_lib.lib().fgnn_osd0(self.handle, int(side), _ptr(marg), _ptr(llr_bin), _ptr(synd), B, _ptr(index), int(nact),
+                                   _ptr(e_hat), _stream(self.device)))
+        return e_hat
+
+    def residual_rows(self, rows_x, rows_z, ex, ez, x_hat, z_hat):
+        B = int(ex.shape[0])
+        ls_hat = self._new((B, self._row_count(rows_x) + self._row_count(rows_z)), torch.uint8)
+        flags = self._new((B,), torch.uint8)
+        check(_lib.lib().fgnn_residual_rows(self.handle, int(rows_x), int(rows_z), _ptr(ex), _ptr(ez), _ptr(x_hat), _ptr(z_hat), B, None,
+                                            _ptr(ls_hat), _ptr(flags), _stream(self.device)))
+        return ls_hat, flags
+
+    def _row_count(self, which):
+        return [self.rows_xp, self.rows_zp, self.rows_hxp, self.rows_hzp, self.rows_lx, self.rows_lz][which]
+
     # ---- binary syndrome BP on the hx graph (LDPCBPDecoder, is_syndrome=True) ----------------------------------
     def bp2_decode(self, synd, num_iter, cn_type="boxplus-phi", factor=1.0, llr_ch=None, llr_const=0.0, B=None, want_soft=True,
                    want_hard=True):

@@ -127,6 +127,10 @@ int fgnn_merge(const uint8_t* errors, const uint8_t* x_upd, const uint8_t* z_upd
  * (= what count_block_errors sees, sionna/utils/metrics.py:221-223 via misc.py:649-651). */
 int fgnn_residual(const fgnn_graph* g, const uint8_t* noise_x, const uint8_t* noise_z, const uint8_t* x_hat,
                   const uint8_t* z_hat, int B, uint8_t* s_hat, uint8_t* ls_hat, uint8_t* flags, void* stream);
+/* Same with the two row sets chosen by the caller: ls_hat = [rows_x . xd ; rows_z . zd], e.g. (FGNN_ROWS_LZ, FGNN_ROWS_LX) for
+ * BP4_OSD_Model.call, bp_osd.py:184-188. */
+int fgnn_residual_rows(const fgnn_graph* g, int rows_x, int rows_z, const uint8_t* noise_x, const uint8_t* noise_z,
+                       const uint8_t* x_hat, const uint8_t* z_hat, int B, uint8_t* s_hat, uint8_t* ls_hat, uint8_t* flags, void* stream);
 /* counts[0] += #flagged, counts[1] += #block errors, counts[2] += B (device uint64[3]), misc.py:649-669. */
 int fgnn_count_flags(const uint8_t* flags, int B, uint64_t* counts, void* stream);
 
@@ -151,6 +155,21 @@ int fgnn_bp2_decode(const fgnn_graph* g, int cn_type, int num_iter, float normal
                     float llr_const, const uint8_t* synd, int B, float* soft_out, uint8_t* hard_out, void* stream);
 /* BinarySymmetricChannel on the all-zero word, BP_BSC_Model.call feedback_gnn.py:213-214: noise = u < p (Philox stream). */
 int fgnn_bsc_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, uint8_t* noise, void* stream);
+
+/* OSD-0 post-processing of BP failures — OSD0_Decoder.call / find_mrb, sionna/fec/ldpc/bp_osd.py:14-77, as driven by
+ * BP4_OSD_Model.call_osd (:138-157).  fgnn_graph_set_basis installs code.pivot_hx (side 0) or
+ * code.pivot_hz (side 1) (host array): the rows hx[pivot_hx] form the full-rank matrix of :147-150.  fgnn_osd0 solves, for
+ * every listed sample, H_basis e = syndrome on the most reliable independent columns and writes e_hat[b,:]:
+ * side 0 -> z_hat from hx and osd_llrz, side 1 -> x_hat from hz and osd_llrx (:125-131), computed from the BP4 marginals
+ * marg [B,3,n], or from llr_bin [B,n] if given (BP2_OSD_Model).  synd [B,m_side] is the FULL syndrome (reduced
+ * internally, :144-145).  index (device int32[nact]) selects the samples to process, NULL = all B.
+ * Ties in the reliability sort keep qubit order (tf.argsort leaves them unspecified). */
+int fgnn_graph_set_basis(fgnn_graph* g, int side, int rank, const int32_t* pivot_rows);
+int fgnn_osd0(const fgnn_graph* g, int side, const float* marg, const float* llr_bin, const uint8_t* synd, int B,
+              const int32_t* index, int nact, uint8_t* e_hat, void* stream);
+/* index[0..*count) = ids b with (mask[b] & bit) != 0 (tf.where(err), bp_osd.py:166-171); *count (device int32) must be
+ * zero on entry; ids of one 256-sample block are ascending, blocks arrive in any order. */
+int fgnn_compact(const uint8_t* mask, int bit, int B, int32_t* index, int32_t* count, void* stream);
 
 /* GNN_BP4 (the syndrome-only "full GNN" decoder), sionna/fec/ldpc/gnn.py:71-423 with UpdateCNEmbeddings (:426-610)
  * and UpdateVNEmbeddings (:612-751): num_mlp_layers=2, tanh, mean, use_bias, num_embed_dims=20, num_hidden_units=40.

@@ -868,6 +868,93 @@ int og_bsc_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, ui
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * OSD0_Decoder.call + find_mrb, sionna/fec/ldpc/bp_osd.py:14-77, as used by BP4_OSD_Model.call_osd (:138-157):
+ * for one side s (0: hx with llr_z -> z_hat, 1: hz with llr_x -> x_hat) solve H_basis e = s_reduced with the
+ * rows H[pivot[r]] (code.pivot_hx / pivot_hz, hx_basis = hx[pivot_hx], codes_q.py:39-40) after sorting the columns by
+ * ascending reliability.  tf.argsort is unstable (ties in arbitrary order); the build's canonical order is the
+ * stable one (ties -> lower qubit index first).  Row by row: pivot = first 1 of the current row (tf.argmax over the
+ * n+1 augmented columns, :29), Gauss-Jordan elimination of that column from every other row (:33-42);
+ * e_hat[order[pivot_r]] = transformed syndrome bit r (:44-45, :68-69).
+ * marg [B,3,n] are BP4 marginals (X,Y,Z planes); the binary reliabilities are those of generate_noise_and_bp4
+ * (:125-131): osd_llrz = softplus(-X) - lse(-Z,-Y) for side 0, osd_llrx = softplus(-Z) - lse(-X,-Y) for side 1.
+ * If llr_bin != NULL it is used instead ([B,n], BP2_OSD_Model).  index/nact: optional list of sample ids to process.
+ * ------------------------------------------------------------------------------------------ */
+int og_osd0(const og_graph* g, int side, int rank, const int32_t* pivot_rows, const float* marg, const float* llr_bin,
+            const uint8_t* synd, int B, const int32_t* index, int nact, uint8_t* e_hat)
+{
+    const int n = g->n, ms = g->m[side];
+    const int count = index ? nact : B;
+#pragma omp parallel
+    {
+        float* key = (float*)malloc(sizeof(float) * (size_t)n);
+        int* order = (int*)malloc(sizeof(int) * (size_t)n * 2);
+        int* inv = order + n;
+        uint8_t* M = (uint8_t*)malloc((size_t)rank * (size_t)(n + 1));
+        uint8_t* ep = (uint8_t*)malloc((size_t)n);
+#pragma omp for schedule(dynamic, 1)
+        for (int t = 0; t < count; ++t) {
+            const int b = index ? index[t] : t;
+            for (int v = 0; v < n; ++v) {
+                if (llr_bin) key[v] = llr_bin[(size_t)b * n + v];
+                else {
+                    const float* mg = marg + (size_t)b * 3 * n;
+                    const float X = mg[v], Y = mg[n + v], Z = mg[2 * n + v];
+                    key[v] = side == 0 ? fg_softplus(-X) - fg_lse2(-Z, -Y) : fg_softplus(-Z) - fg_lse2(-X, -Y);
+                }
+                order[v] = v;
+            }
+            /* stable ascending insertion-merge: simple O(n log n) bottom-up merge sort on indices */
+            {
+                int* tmp = (int*)malloc(sizeof(int) * (size_t)n);
+                for (int w = 1; w < n; w *= 2) {
+                    for (int lo = 0; lo < n; lo += 2 * w) {
+                        int mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n, i = lo, j = mid, k = lo;
+                        while (i < mid && j < hi) tmp[k++] = (key[order[j]] < key[order[i]]) ? order[j++] : order[i++];
+                        while (i < mid) tmp[k++] = order[i++];
+                        while (j < hi) tmp[k++] = order[j++];
+                    }
+                    memcpy(order, tmp, sizeof(int) * (size_t)n);
+                }
+                free(tmp);
+            }
+            for (int j = 0; j < n; ++j) inv[order[j]] = j;
+            memset(M, 0, (size_t)rank * (size_t)(n + 1));
+            for (int r = 0; r < rank; ++r) {
+                const int c = pivot_rows[r];
+                for (int jx = g->cptr[side][c]; jx < g->cptr[side][c + 1]; ++jx) M[(size_t)r * (n + 1) + inv[g->cvn[side][jx]]] = 1;
+                M[(size_t)r * (n + 1) + n] = synd[(size_t)b * ms + c] & 1;
+            }
+            memset(ep, 0, (size_t)n);
+            for (int r = 0; r < rank; ++r) {
+                uint8_t* row = M + (size_t)r * (n + 1);
+                int p = 0;
+                while (p <= n && !row[p]) ++p;
+                if (p > n) p = 0; /* all-zero row: tf.argmax returns 0 */
+                for (int i = 0; i < rank; ++i) {
+                    if (i == r) continue;
+                    uint8_t* ri = M + (size_t)i * (n + 1);
+                    if (ri[p])
+                        for (int k = p; k <= n; ++k) ri[k] ^= row[k];
+                }
+            }
+            /* the syndrome bit of row r is final only after ALL eliminations: re-read it */
+            for (int r = 0; r < rank; ++r) {
+                const uint8_t* row = M + (size_t)r * (n + 1);
+                int p = 0;
+                while (p <= n && !row[p]) ++p;
+                if (p < n) ep[p] = row[n];
+            }
+            for (int j = 0; j < n; ++j) e_hat[(size_t)b * n + order[j]] = ep[j];
+        }
+        free(key);
+        free(order);
+        free(M);
+        free(ep);
+    }
+    return 0;
+}
+
 /* elementwise wrappers so tests can probe the shared math from Python */
 void og_math_apply(int fn, const float* x, float* y, long nelem)
 {

@@ -50,6 +50,7 @@ def lib():
         _lib.og_philox.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.og_bp2_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib.og_bsc_noise.argtypes = [C.c_uint64, C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
+        _lib.og_osd0.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         _lib.og_gnn_bp4.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5
     return _lib
 
@@ -251,3 +252,20 @@ class OracleGraph:
         e = np.empty((B, self.n), np.uint8)
         lib().og_bsc_noise(int(seed), float(np.float32(p)), int(first_sample), B, self.n, _p(e))
         return e
+
+    # -- OSD-0 (bp_osd.py:14-77) -------------------------------------------------------------------------------
+    def osd0(self, side, pivot_rows, synd, marg=None, llr_bin=None, index=None, e_hat=None):
+        piv = np.ascontiguousarray(pivot_rows, dtype=np.int32)
+        synd = np.ascontiguousarray(synd, dtype=np.uint8)
+        B = synd.shape[0]
+        if marg is not None:
+            marg = np.ascontiguousarray(marg, dtype=np.float32)
+        if llr_bin is not None:
+            llr_bin = np.ascontiguousarray(llr_bin, dtype=np.float32)
+        idx = None if index is None else np.ascontiguousarray(index, dtype=np.int32)
+        if e_hat is None:
+            e_hat = np.zeros((B, self.n), np.uint8)
+        rc = lib().og_osd0(self.h, int(side), len(piv), _p(piv), _p(marg), _p(llr_bin), _p(synd), B, _p(idx),
+                           0 if idx is None else len(idx), _p(e_hat))
+        assert rc == 0
+        return e_hat

@@ -337,3 +337,52 @@ def test_bp_bsc_model_contract_and_published_band():
     llr = torch.full((64, 882), float(-np.log(0.8 / 0.2)), dtype=torch.float32, device="cuda")
     out = dec((llr, synd.t()))
     assert torch.equal(out, noise_hat)
+
+
+@pytest.mark.parametrize("name,p", [("ghp882", 0.10), ("gb48", 0.09), ("ghp1270", 0.10)])
+def test_osd0_bit_exact_and_solves_the_syndrome(name, p):
+    """OSD-0 (bp_osd.py:14-77) on the BP failures: kernel vs oracle, and H e_hat = syndrome for every processed sample."""
+    c = code(name)
+    B = 256
+    og, gg = oracle_graph(name), gpu_graph(name)
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, p, B, first=5)
+    L0 = llr_const(p)
+    o = og.bp4_decode(sx, sz, 30, "minsum", 0.8, llr_const=L0)
+    g = gg.bp4_decode(tx, tz, 30, "minsum", 0.8, llr_const=L0, want_logits=False)
+    fl = og.residual(ex, ez, o["x_hat"], o["z_hat"])[2]
+    idx = np.nonzero(fl & 1)[0].astype(np.int32)
+    assert len(idx) >= 3, "test point must produce BP failures"
+    gfl = gg.residual(gx, gz, g["x_hat"], g["z_hat"], want_arrays=False)[2]
+    gi, nact = gg.compact(gfl, 1)
+    assert nact == len(idx) and sorted(gi[:nact].cpu().numpy().tolist()) == idx.tolist()
+    gg.set_basis(0, c.pivot_hx)
+    gg.set_basis(1, c.pivot_hz)
+    zh, xh = o["z_hat"].copy(), o["x_hat"].copy()
+    og.osd0(0, c.pivot_hx, sx, marg=o["llr"], index=idx, e_hat=zh)
+    og.osd0(1, c.pivot_hz, sz, marg=o["llr"], index=idx, e_hat=xh)
+    gg.osd0(0, tx, g["z_hat"], marg=g["llr"], index=gi, nact=nact)
+    gg.osd0(1, tz, g["x_hat"], marg=g["llr"], index=gi, nact=nact)
+    assert np.array_equal(zh, g["z_hat"].cpu().numpy()) and np.array_equal(xh, g["x_hat"].cpu().numpy())
+    assert np.array_equal(zh[idx].astype(np.int64) @ c.hx.T % 2, sx[idx]) and np.array_equal(xh[idx].astype(np.int64) @ c.hz.T % 2, sz[idx])
+    # ties: saturated marginals give many equal reliabilities — run OSD on a converged sample too (stable order must agree)
+    ok = np.nonzero((fl & 1) == 0)[0][:4].astype(np.int32)
+    z2, x2 = o["z_hat"].copy(), o["x_hat"].copy()
+    og.osd0(0, c.pivot_hx, sx, marg=o["llr"], index=ok, e_hat=z2)
+    gz2 = g["z_hat"].clone()
+    gg.osd0(0, tx, gz2, marg=g["llr"], index=to_gpu(ok), nact=len(ok))
+    assert np.array_equal(z2[ok], gz2.cpu().numpy()[ok])
+    assert np.array_equal(z2[ok].astype(np.int64) @ c.hx.T % 2, sx[ok])
+
+
+def test_bp4_osd_model_published_band():
+    """examples/OSD.ipynb cell 2: [[882,24]], min-sum BP4 100 it factor 0.8 + OSD-0: p=0.10 -> BLER 3.70e-4 (111/300 000)."""
+    import feedback_gnn_amd as F
+    c = code("ghp882")
+    dec = F.QLDPCBPDecoder(code=c, num_iter=100, normalization_factor=0.8, cn_type="minsum", stage_one=True)
+    model = F.BP4_OSD_Model(c, dec, F.OSD0_Decoder(c.N))
+    zeros, ls_hat = model(300000, 0.10)
+    assert ls_hat.shape == (300000, 48) and not bool(zeros.any())
+    errs = int(ls_hat.any(1).sum())
+    # Poisson band around 111 events (two independent draws): 4 sigma
+    assert abs(errs - 111) < 4 * np.sqrt(2 * 111), errs
+    assert 0.002 < model.last_num_osd / 300000 < 0.05  # BP failure rate at p=0.10 is ~1 %
