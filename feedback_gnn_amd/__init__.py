@@ -26,7 +26,7 @@ def __getattr__(name):
     if name in ("LDPCBPDecoder", "BP_BSC_Model"):
         from . import decoding as _d
         return getattr(_d, name)
-    if name in ("OSD0_Decoder", "BP4_OSD_Model"):
+    if name in ("OSD0_Decoder", "BP4_OSD_Model", "BP2_OSD_Model"):
         from . import bp_osd as _o
         return getattr(_o, name)
     if name == "GNN_BP4":

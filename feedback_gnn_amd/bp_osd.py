@@ -57,3 +57,39 @@ class BP4_OSD_Model:
         return torch.zeros_like(ls_hat), ls_hat
 
     call = __call__
+
+
+class BP2_OSD_Model:
+    """``BP2_OSD_Model(pcm, pcm_basis, pivot_pcm, logical_pcm, bp2_decoder, osd_decoder)``; ``model(batch_size, p)`` →
+    ``(zeros_like(ls_hat), ls_hat[bs, rows(logical_pcm)])`` (bp_osd.py:194-273): BSC(p) noise, binary syndrome BP with soft
+    output, OSD-0 on the samples whose estimate misses the syndrome, ``ls_hat = logical_pcm·(noise xor estimate)``."""
+
+    def __init__(self, pcm, pcm_basis, pivot_pcm, logical_pcm, bp2_decoder, osd_decoder, *, seed=0x5EED, rank=0, world_size=1):
+        from .decoding import _binary_graph
+        self.pcm, self.logical_pcm, self.bp2_decoder, self.osd_decoder = pcm, logical_pcm, bp2_decoder, osd_decoder
+        self.graph = _binary_graph(pcm, logical_pcm, bp2_decoder.graph.device)
+        self.graph.set_basis(0, pivot_pcm)
+        self.seed, self.rank, self.world_size, self._next = int(seed), int(rank), int(world_size), 0
+        self.last_num_osd = 0
+
+    def __call__(self, batch_size, ebno_db=None, **kw):
+        p = float(kw.get("p", ebno_db))
+        B, g, d = int(batch_size), self.graph, self.bp2_decoder
+        first = self._next + self.rank * B
+        self._next += self.world_size * B
+        pf = np.float32(p)
+        llr_const = float(-np.log((np.float32(1.0) - pf) / pf, dtype=np.float32))  # (:216)
+        noise = g.bsc_noise(self.seed, p, first, B)
+        zeros = torch.zeros_like(noise)
+        synd, _ = g.syndrome(zeros, noise)
+        soft, noise_hat = g.bp2_decode(synd, d._num_iter, d._cn_type, d._normalization_factor, llr_const=llr_const, B=B)
+        _, _, flags = g.residual(noise, zeros, noise_hat, zeros, want_arrays=False)
+        index, nact = g.compact(flags, 1)
+        self.last_num_osd = nact
+        if nact:
+            g.osd0(0, synd, noise_hat, llr_bin=(-soft).contiguous(), index=index, nact=nact)  # llr_hat = -decoder output (:225)
+        _, ls_hat, _ = g.residual(noise, zeros, noise_hat, zeros, want_arrays=True)
+        ls_hat = ls_hat[:, :g.rows_hxp].contiguous()
+        return torch.zeros_like(ls_hat), ls_hat
+
+    call = __call__

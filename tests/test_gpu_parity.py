@@ -386,3 +386,48 @@ def test_bp4_osd_model_published_band():
     # Poisson band around 111 events (two independent draws): 4 sigma
     assert abs(errs - 111) < 4 * np.sqrt(2 * 111), errs
     assert 0.002 < model.last_num_osd / 300000 < 0.05  # BP failure rate at p=0.10 is ~1 %
+
+
+def test_bp2_osd_model_published_band():
+    """examples/OSD.ipynb cell 3: binary min-sum BP 100 it (factor 0.8, soft output) + OSD-0 on hx of [[882,24]] over a BSC,
+    logical_pcm = lx: p=0.05 -> BLER 5.85e-4 (117/200 000)."""
+    import feedback_gnn_amd as F
+    c = code("ghp882")
+    bp2 = F.LDPCBPDecoder(c.hx, is_syndrome=True, hard_out=False, cn_type="minsum", num_iter=100, normalization_factor=0.8)
+    model = F.BP2_OSD_Model(c.hx, c.hx_basis, c.pivot_hx, c.lx, bp2, F.OSD0_Decoder(c.N))
+    zeros, ls_hat = model(200000, 0.05)
+    assert ls_hat.shape == (200000, 24) and not bool(zeros.any())
+    errs = int(ls_hat.any(1).sum())
+    assert abs(errs - 117) < 4 * np.sqrt(2 * 117), errs
+    assert model.last_num_osd > 0
+
+
+def test_overcomplete_irregular_graph():
+    """Over-complete check matrices (the reference's GB_*_H_*.alist use case, QLDPC.ipynb cell 5): redundant rows give
+    irregular degrees and qubits with tens of checks; the CSR kernels must still match the oracle bit for bit."""
+    from feedback_gnn_amd import codes_q as cq
+    from feedback_gnn_amd.graph import TannerGraph
+    from oracle.oracle import OracleGraph
+    base = code("gb48")
+    rng = np.random.RandomState(4)
+
+    def overcomplete(h, rows):
+        out = [h]
+        while sum(x.shape[0] for x in out) < rows:
+            pick = rng.choice(h.shape[0], size=rng.randint(2, 4), replace=False)
+            out.append((h[pick].sum(0) % 2)[None, :])
+        return np.vstack(out)[:rows]
+
+    c = cq.css_code(overcomplete(base.hx, 150), overcomplete(base.hz, 130), name="gb48_oc")
+    assert c.K == base.K and len(set(c.hx.sum(1))) > 2 and c.hx.sum(0).max() > 20
+    og, gg = OracleGraph(c), TannerGraph(c)
+    assert gg.info()["regular"] == 0
+    ex, ez = og.pauli_noise(SEED, 0.06, 0, 50)
+    sx, sz = og.syndrome(ex, ez)
+    for cn_type in ("boxplus-phi", "minsum"):
+        o = og.bp4_decode(sx, sz, 6, cn_type, 1.0, llr_const=llr_const(0.3), return_msgs=True)
+        g = gg.bp4_decode(to_gpu(sx), to_gpu(sz), 6, cn_type, 1.0, llr_const=llr_const(0.3), return_msgs=True)
+        _assert_bp_equal(o, g, f"overcomplete {cn_type}")
+    s0, l0, f0 = og.residual(ex, ez, o["x_hat"], o["z_hat"])
+    s1, l1, f1 = gg.residual(to_gpu(ex), to_gpu(ez), g["x_hat"], g["z_hat"])
+    assert np.array_equal(s0, s1.cpu().numpy()) and np.array_equal(f0, f1.cpu().numpy())
