@@ -89,7 +89,7 @@ __device__ __forceinline__ void mlp_tile(const float* __restrict__ lane_tab, int
     // space; each operand is then one coalesced 256-byte L1/L2 load right before its MFMA.)
     int off = first * 64;
     asm volatile("" : "+v"(off));
-    const float* tab = lane_tab + off;
+    const float* tab = lane_tab + off;  // lane_tab points into LDS (the phase's tables are staged there)
     const f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     f4 d[3] = {zero, zero, zero};
 #pragma unroll
@@ -277,12 +277,16 @@ __global__ void __launch_bounds__(256) gnn_bp4_kernel(GraphDev g, GnnBp4Dev w, A
 }
 
 template <int DV, int DC>
-__global__ void __launch_bounds__(256, 4) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4Dev w, Args a)
+__global__ void __launch_bounds__(512, 2) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4Dev w, Args a, int tab_floats)
 {
+    // LDS: [tab_floats] the current phase's per-lane operand tables (staged from L2 at every phase start: operand
+    // reads then cost an LDS access instead of an L2 round trip, which is what the waves were waiting on), then
+    // lx | lz | hlog.  512 threads = 8 waves share the staged tables; two workgroups fit a CU.
     extern __shared__ float lds[];
-    const int b = blockIdx.x, tid = threadIdx.x, T = 256;
+    const int b = blockIdx.x, tid = threadIdx.x, T = 512, NW = 8;
     const int n = g.n, mx = g.m_x, mz = g.m_z, m = g.m;
-    float* lx = lds;
+    float* tabs = lds;
+    float* lx = lds + tab_floats;
     float* lz = lx + n;
     float* hlog = lz + n;
     float* hv = a.work + (size_t)b * (size_t)(n + m) * D;
@@ -293,15 +297,19 @@ __global__ void __launch_bounds__(256, 4) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4
     for (int i = tid; i < n * D; i += T) hv[i] = 1.0f;
     for (int i = tid; i < m * D; i += T) hc[i] = 0.0f;
     for (int c = tid; c < m; c += T) hlog[c] = 0.0f;
-    __syncthreads();
     float* llr = a.llr_out + (size_t)b * 3 * n;
     const int l = tid & 63, wave = tid >> 6, j = l & 15, q = l >> 4;
-    const float* tab = w.lane_tab + l;
+    const float* tab = tabs + l;
     const int vtiles = (n + 15) >> 4, xtiles = (mx + 15) >> 4, ztiles = (mz + 15) >> 4;
+    // phase tables are contiguous in the global table: CN phase = [tab_cn_msg[0], tab_vn_msg[0]), VN phase = the rest
+    const int cn_first = w.tab_cn_msg[0], vn_first = w.tab_vn_msg[0], vn_end = w.tab_inv + 8;
     for (int it = -1; it < a.num_iter; ++it) {
         if (it >= 0) {
+            __syncthreads();
+            for (int i = tid; i < (vn_end - vn_first) * 64; i += T) tabs[i] = w.lane_tab[(size_t)vn_first * 64 + i];
+            __syncthreads();
             // ---- UpdateVNEmbeddings on tiles of 16 qubits ----
-            for (int tile = wave; tile < vtiles; tile += 4) {
+            for (int tile = wave; tile < vtiles; tile += NW) {
                 const int vraw = tile * 16 + j;
                 const bool valid = vraw < n;
                 const int v = valid ? vraw : n - 1;
@@ -319,7 +327,7 @@ __global__ void __launch_bounds__(256, 4) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4
                         load_row5(hc + (size_t)((s2 ? mx : 0) + c) * D, q, fr);
 #pragma unroll
                         for (int s = 0; s < 5; ++s) { Bin[s] = fr[s]; Bin[5 + s] = own[s]; }
-                        mlp_tile<10>(tab, w.tab_vn_msg[s2], Bin, msg);
+                        mlp_tile<10>(tab, w.tab_vn_msg[s2] - vn_first, Bin, msg);
                         const float sg = ((s2 ? sz[c] : sx[c]) & 1) ? -1.0f : 1.0f;
 #pragma unroll
                         for (int i = 0; i < 5; ++i) { const float mv = msg[i] * sg; acc[i] = (k == 0) ? mv : acc[i] + mv; }
@@ -330,11 +338,11 @@ __global__ void __launch_bounds__(256, 4) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4
 #pragma unroll
                 for (int i = 0; i < 5; ++i) Bemb[10 + i] = own[i];
                 float nh[5];
-                mlp_tile<15>(tab, w.tab_vn_embed, Bemb, nh);
+                mlp_tile<15>(tab, w.tab_vn_embed - vn_first, Bemb, nh);
                 // embed_to_llr: L^T = Winv^T nh^T (rows 0..2 land on lane group 0, registers 0..2)
                 const f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
                 f4 o = zero;
-                int offi = w.tab_inv * 64;
+                int offi = (w.tab_inv - vn_first) * 64;
                 asm volatile("" : "+v"(offi));
                 const float* ti = tab + offi;
 #pragma unroll
@@ -367,11 +375,13 @@ __global__ void __launch_bounds__(256, 4) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4
             if (zl)
                 for (int r = tid; r < g.rows[4]; r += T)
                     zl[mx + r] = logit_row_gnn(lz, g.rcol[4] + g.rptr[4][r], g.rptr[4][r + 1] - g.rptr[4][r]);
-            __syncthreads();
             if (it == a.num_iter - 1) break;
         }
+        __syncthreads();
+        for (int i = tid; i < (vn_first - cn_first) * 64; i += T) tabs[i] = w.lane_tab[(size_t)cn_first * 64 + i];
+        __syncthreads();
         // ---- UpdateCNEmbeddings: tiles never mix hx and hz checks (the two sides use different weights) ----
-        for (int tile = wave; tile < xtiles + ztiles; tile += 4) {
+        for (int tile = wave; tile < xtiles + ztiles; tile += NW) {
             const int s2 = tile >= xtiles;
             const int local = (s2 ? tile - xtiles : tile) * 16 + j;
             const int cnt = s2 ? mz : mx;
@@ -386,7 +396,7 @@ __global__ void __launch_bounds__(256, 4) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4
                 load_row5(hv + (size_t)v * D, q, fr);
 #pragma unroll
                 for (int s = 0; s < 5; ++s) { Bin[s] = fr[s]; Bin[5 + s] = own[s]; }
-                mlp_tile<10>(tab, w.tab_cn_msg[s2], Bin, msg);
+                mlp_tile<10>(tab, w.tab_cn_msg[s2] - cn_first, Bin, msg);
 #pragma unroll
                 for (int i = 0; i < 5; ++i) acc[i] = (k == 0) ? msg[i] : acc[i] + msg[i];
             }
@@ -396,11 +406,11 @@ __global__ void __launch_bounds__(256, 4) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4
             const float lg = (it >= 0) ? hlog[c] * (sb ? -1.0f : 1.0f) : 0.0f;
             Bemb[10] = (q == 0) ? lg : 0.0f;
             float nh[5];
-            mlp_tile<11>(tab, w.tab_cn_embed[s2], Bemb, nh);
+            mlp_tile<11>(tab, w.tab_cn_embed[s2] - cn_first, Bemb, nh);
             if (valid) store_row5(hc + (size_t)c * D, q, nh);
         }
-        __syncthreads();
     }
+    __syncthreads();
     for (int v = tid; v < n; v += T) {
         const float X = llr[v], Y = llr[n + v], Z = llr[2 * n + v];
         int d = 0;
@@ -577,7 +587,13 @@ extern "C" int fgnn_gnnbp4_decode(const fgnn_graph* g, const fgnn_gnnbp4_weights
     a.work = static_cast<float*>(workspace);
     const size_t lds_bytes = (size_t)(2 * g->d.n + g->d.m) * sizeof(float);
     if (g->d.dvx == 3 && g->d.dvz == 3 && g->d.dc == 6 && !g->force_generic) {
-        hipLaunchKernelGGL((gnn_bp4_mfma_kernel<3, 6>), dim3(B), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), g->d, w->d, a);
+        const int cn_entries = w->d.tab_vn_msg[0] - w->d.tab_cn_msg[0], vn_entries = w->d.tab_inv + 8 - w->d.tab_vn_msg[0];
+        const int tab_floats = (cn_entries > vn_entries ? cn_entries : vn_entries) * 64;
+        const size_t lds2 = lds_bytes + (size_t)tab_floats * sizeof(float);
+        auto kern = gnn_bp4_mfma_kernel<3, 6>;
+        if (lds2 > 160 * 1024) return fgnn_fail(FGNN_ERR_ARG, "code too large for the GNN_BP4 MFMA kernel");
+        FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds2, static_cast<hipStream_t>(stream), g->d, w->d, a, tab_floats);
         FGNN_HIP_CHECK(hipGetLastError());
         return FGNN_OK;
     }

@@ -1,0 +1,12 @@
+import sys, torch, numpy as np
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from helpers import code
+from feedback_gnn_amd.graph import TannerGraph, GnnBp4Weights, GNNBP4_SHAPES
+B = 4096
+g = TannerGraph(code('ghp1270'))
+rng = np.random.RandomState(0)
+w = GnnBp4Weights([rng.uniform(-0.3, 0.3, size=s).astype(np.float32) for s in GNNBP4_SHAPES], g.device)
+ex, ez = g.pauli_noise(0x5EED, 0.05, 0, B); sx, sz = g.syndrome(ex, ez)
+for _ in range(2):
+    g.gnn_bp4_decode(w, sx, sz, 10, return_logits=False)
+torch.cuda.synchronize(); print("done")
