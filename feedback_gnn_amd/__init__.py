@@ -17,7 +17,8 @@ def __getattr__(name):
     if name in ("QLDPCBPDecoder",):
         from .decoding_q import QLDPCBPDecoder
         return QLDPCBPDecoder
-    if name in ("Feedback_GNN", "Sandwich_BP_GNN_Evaluation_Model", "Pauli", "load_weights"):
+    if name in ("Feedback_GNN", "Sandwich_BP_GNN_Evaluation_Model", "Pauli", "load_weights", "First_Stage_BP_Model",
+                "Second_Stage_GNN_BP_Model"):
         from . import feedback_gnn as _f
         return getattr(_f, name)
     if name in ("sim_ber", "count_block_errors", "PlotBER"):

@@ -31,6 +31,44 @@ __global__ void __launch_bounds__(256) pauli_kernel(uint64_t seed, float p, uint
         }
 }
 
+// Pauli.call with wt=True (pauli.py:80-97).  One wave per sample: its lanes zero the two rows and fill the identity
+// permutation in LDS, lane 0 runs the `wt` Fisher-Yates steps (tens of dependent LDS accesses — noise generation is
+// < 0.1 % of a Monte-Carlo step) and marks the chosen qubits.
+__global__ void __launch_bounds__(256) pauli_wt_kernel(uint64_t seed, int wt, uint64_t first, int B, int n, uint8_t* __restrict__ ex,
+                                                       uint8_t* __restrict__ ez)
+{
+    extern __shared__ unsigned short perm_all[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    unsigned short* perm = perm_all + (size_t)wave * n;
+    uint8_t* rx = ex + (size_t)b * n;
+    uint8_t* rz = ez + (size_t)b * n;
+    for (int v = lane; v < n; v += 64) {
+        perm[v] = (unsigned short)v;
+        rx[v] = 0;
+        rz[v] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane != 0) return;
+    float up[4] = {0, 0, 0, 0}, ut[4] = {0, 0, 0, 0};
+    for (int i = 0; i < wt; ++i) {
+        if ((i & 3) == 0) {
+            fg_uniform4s(seed, first + (uint64_t)b, (uint32_t)(i >> 2), 1u, up);
+            fg_uniform4s(seed, first + (uint64_t)b, (uint32_t)(i >> 2), 2u, ut);
+        }
+        const int j = i + fg_fy_pick(up[i & 3], n - i);
+        const unsigned short t = perm[i];
+        perm[i] = perm[j];
+        perm[j] = t;
+        const float u = ut[i & 3];
+        rx[perm[i]] = (uint8_t)(u < (2.0f / 3.0f));
+        rz[perm[i]] = (uint8_t)(u > (1.0f / 3.0f));
+    }
+}
+
 __device__ __forceinline__ unsigned row_parity(const uint8_t* x, const int* __restrict__ col, int p0, int p1)
 {
     unsigned a = 0;
@@ -187,6 +225,17 @@ extern "C" int fgnn_pauli_noise(uint64_t seed, float p, uint64_t first_sample, i
     const long long total = (long long)B * nblk;
     hipLaunchKernelGGL(pauli_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), seed,
                        p, first_sample, B, n, nblk, noise_x, noise_z);
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_pauli_noise_wt(uint64_t seed, int wt, uint64_t first_sample, int B, int n, uint8_t* noise_x, uint8_t* noise_z,
+                                   void* stream)
+{
+    if (B < 0 || n <= 0 || n > 65535 || wt < 0 || wt > n || !noise_x || !noise_z) return fgnn_fail(FGNN_ERR_ARG, "bad fixed-weight noise arguments");
+    if (B == 0) return FGNN_OK;
+    hipLaunchKernelGGL(pauli_wt_kernel, dim3((B + 3) / 4), dim3(256), (size_t)4 * n * sizeof(unsigned short),
+                       static_cast<hipStream_t>(stream), seed, wt, first_sample, B, n, noise_x, noise_z);
     FGNN_HIP_CHECK(hipGetLastError());
     return FGNN_OK;
 }

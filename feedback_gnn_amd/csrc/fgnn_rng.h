@@ -44,6 +44,28 @@ FG_FN void fg_uniform4(uint64_t seed, uint64_t sample, uint32_t block, float u[4
     u[3] = fg_u32_to_unit(r[3]);
 }
 
+/* same with an explicit stream id in the 4th counter word (0 = i.i.d. channel noise, 1 = fixed-weight positions,
+ * 2 = fixed-weight Pauli types) */
+FG_FN void fg_uniform4s(uint64_t seed, uint64_t sample, uint32_t block, uint32_t stream, float u[4])
+{
+    uint32_t r[4];
+    fg_philox4x32_10((uint32_t)sample, (uint32_t)(sample >> 32), block, stream, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    u[0] = fg_u32_to_unit(r[0]);
+    u[1] = fg_u32_to_unit(r[1]);
+    u[2] = fg_u32_to_unit(r[2]);
+    u[3] = fg_u32_to_unit(r[3]);
+}
+
+/* Fixed-weight errors, Pauli.call wt branch (pauli.py:80-97): `wt` distinct positions (first wt entries of a uniform
+ * shuffle) and per position u ~ U[0,1): X component iff u < 2/3, Z component iff u > 1/3.  The build's stream:
+ * partial Fisher-Yates, step i swaps perm[i] with perm[i + min(floor(u_i*(n-i)), n-i-1)], u_i from stream 1,
+ * the type uniform of position i from stream 2.  `perm` is caller scratch of n entries (identity on entry). */
+FG_FN int fg_fy_pick(float u, int remaining)
+{
+    int j = (int)(u * (float)remaining);
+    return j < remaining - 1 ? j : remaining - 1;
+}
+
 /* Pauli.call thresholds (pauli.py:100-108) for px = pz = 2p/3, py = p/3 (feedback_gnn.py:298),
  * evaluated in float32 like the reference's tf.float32 graph:
  *   noise_x = u < px ;  noise_z = (u >= px - py) & (u < (px + pz) - py). */

@@ -1,8 +1,8 @@
 """Feedback_GNN and the BP/GNN sandwich evaluation model on MI355X.
 
 Drop-ins for `sionna.fec.ldpc.Feedback_GNN` and `Sandwich_BP_GNN_Evaluation_Model`
-(/root/reference sionna/fec/ldpc/feedback_gnn.py:20-188, :232-361) and for the non-weight branch of
-`sionna.channel.Pauli` (sionna/channel/pauli.py:98-108).  All device work goes through
+(/root/reference sionna/fec/ldpc/feedback_gnn.py:20-188, :232-361), `First_Stage_BP_Model` / `Second_Stage_GNN_BP_Model`
+(:364-463, forward only) and `sionna.channel.Pauli` (sionna/channel/pauli.py:80-108).  All device work goes through
 libfgnn_hip.so (include/fgnn.h); tensors are torch tensors on the HIP device.
 """
 import numpy as np
@@ -95,7 +95,7 @@ def load_weights(system, model_path):
 
 
 class Pauli:
-    """i.i.d. Pauli channel, non-weight branch of sionna/channel/pauli.py:98-108.
+    """i.i.d. Pauli channel (sionna/channel/pauli.py:98-108) and, with ``wt=True``, the fixed-weight channel of :80-97.
 
     ``Pauli(graph)((batch_size, px, py, pz))`` is not how the reference is called; the sandwich
     model only ever uses px = pz = 2p/3, py = p/3 (feedback_gnn.py:298), which is what the library
@@ -105,13 +105,15 @@ class Pauli:
     """
 
     def __init__(self, graph, seed=0x5EED, wt=False):
-        if wt:
-            raise NotImplementedError("fixed-weight noise (training-set harvesting, pauli.py:80-97) is not on the "
-                                      "evaluation hot path")
         self.graph = graph
         self.seed = int(seed)
+        self.wt = bool(wt)
 
     def __call__(self, batch_size, p, first_sample=0):
+        """``p`` = physical error rate, or with ``wt=True`` the exact number of erroneous qubits per sample
+        (pauli.py:80-97: positions uniform without replacement, X/Y/Z with probability 1/3 each)."""
+        if self.wt:
+            return self.graph.pauli_noise_wt(self.seed, int(p), first_sample, int(batch_size))
         return self.graph.pauli_noise(self.seed, p, first_sample, int(batch_size))
 
 
@@ -131,8 +133,8 @@ class Sandwich_BP_GNN_Evaluation_Model:
 
     def __init__(self, code, decoders, feedbacks, num_layers=4, wt=False, p0=0.05, *, seed=0x5EED, compact=False,
                  rank=0, world_size=1, output_dtype=torch.uint8):
-        if wt:
-            raise NotImplementedError("wt=True (fixed-weight training noise) is not on the evaluation hot path")
+        if wt and p0 is None:
+            raise ValueError("wt=True needs an explicit p0: the second argument of call() is then an error weight, not a rate")
         if len(decoders) < num_layers or len(feedbacks) < num_layers - 1:
             raise ValueError("need num_layers decoders and num_layers-1 feedbacks")
         self.k, self.n = code.K, code.N
@@ -145,7 +147,7 @@ class Sandwich_BP_GNN_Evaluation_Model:
         self.graph = decoders[0].graph
         if not self.graph.stage_one:
             raise ValueError("the sandwich needs stage_one decoders (decoding_q.py:792-793)")
-        self.channel = Pauli(self.graph, seed=seed)
+        self.channel = Pauli(self.graph, seed=seed, wt=wt)
         self.compact = bool(compact)
         self.rank, self.world_size = int(rank), int(world_size)
         self.output_dtype = output_dtype
@@ -168,7 +170,7 @@ class Sandwich_BP_GNN_Evaluation_Model:
         B = int(batch_size)
         g = self.graph
         first = self._take_samples(B) if first_sample is None else int(first_sample)
-        ex, ez = self.channel(B, float(p), first)
+        ex, ez = self.channel(B, p, first)
         sx, sz = g.syndrome(ex, ez)
         if self._ws_batch != B:
             self._workspace = g.sandwich_workspace(B)
@@ -192,8 +194,66 @@ class Sandwich_BP_GNN_Evaluation_Model:
 
     call = __call__
 
+    def failures(self, batch_size, p):
+        """Noise of the samples the whole sandwich fails to bring back to the syndrome — what the reference's
+        notebook model `BP4_Error_Model` returns (examples/Generate_dataset.ipynb cells 1, 5, 10): ``(noise_x[err], noise_z[err])``."""
+        o = self.decode(batch_size, p)
+        _, _, flags = self.graph.residual(o["noise_x"], o["noise_z"], o["x_hat"], o["z_hat"], want_arrays=False)
+        err = (flags & 1).bool()
+        return o["noise_x"][err], o["noise_z"][err]
+
     def mc_step(self, batch_size, p, counts):
         """One Monte-Carlo batch with on-device counting (sim_ber's qldpc branch, misc.py:647-669)."""
         o = self.decode(batch_size, p)
         _, _, flags = self.graph.residual(o["noise_x"], o["noise_z"], o["x_hat"], o["z_hat"], want_arrays=False)
         return self.graph.count_flags(flags, counts)
+
+
+class First_Stage_BP_Model:
+    """``First_Stage_BP_Model(code, decoder, p0=0.05)``; ``model(noise_x, noise_z)`` → ``(h_vn[bs,n,3], logit_hx_perp, logit_hz_perp)``:
+    the first BP block of the training pipeline on GIVEN noise (feedback_gnn.py:364-392)."""
+
+    def __init__(self, code, decoder, p0=0.05):
+        self.hx, self.hz, self.decoder, self.p0 = code.hx, code.hz, decoder, p0
+
+    def __call__(self, noise_x, noise_z):
+        g = self.decoder.graph
+        ex = torch.as_tensor(noise_x, device=g.device).to(torch.uint8).contiguous()
+        ez = torch.as_tensor(noise_z, device=g.device).to(torch.uint8).contiguous()
+        sx, sz = g.syndrome(ex, ez)
+        p0 = np.float32(self.p0)
+        L = float(np.log(np.float32(3.0) * (np.float32(1.0) - p0) / p0, dtype=np.float32))
+        d = self.decoder
+        o = g.bp4_decode(sx, sz, d.num_iter, d.cn_type, d.normalization_factor, llr_const=L)
+        return o["llr"].permute(0, 2, 1).contiguous(), o["x_logit"].t(), o["z_logit"].t()
+
+    call = __call__
+
+
+class Second_Stage_GNN_BP_Model:
+    """Forward pass of the training objective (feedback_gnn.py:395-463): GNN → BP with per-iteration soft syndromes →
+    ``loss = sum_{i=loss_from}^{num_iter-1} BCE(1-syndrome_z, x_logit_i) + BCE(1-syndrome_x, z_logit_i)`` plus the residual
+    check.  ``model(noise_x, noise_z, h_vn, logit_hx_perp, logit_hz_perp)`` → ``(s_hat, ls_hat, loss)``.  The loss is a value
+    only: the kernels have no backward pass yet, so this class evaluates and monitors training
+    objectives but cannot update ``feedback``."""
+
+    def __init__(self, code, feedback, decoder, num_iter=16, trainable=True, loss_from=8):
+        self.feedback, self.decoder, self.num_iter, self.loss_from, self.trainable = feedback, decoder, int(num_iter), int(loss_from), trainable
+
+    def __call__(self, noise_x, noise_z, h_vn, logit_hx_perp, logit_hz_perp):
+        g = self.decoder.graph
+        ex = torch.as_tensor(noise_x, device=g.device).to(torch.uint8).contiguous()
+        ez = torch.as_tensor(noise_z, device=g.device).to(torch.uint8).contiguous()
+        sx, sz = g.syndrome(ex, ez)
+        new_llr = self.feedback((h_vn, logit_hz_perp, logit_hx_perp, sx.t(), sz.t()))  # the swap of :436
+        llr_hat, x_hat, z_hat = self.decoder((new_llr.permute(0, 2, 1).contiguous(), sx.t(), sz.t()))
+        gt_x = (1 - sz).to(torch.float32)  # labels flipped for BCE (:431-432)
+        gt_z = (1 - sx).to(torch.float32)
+        bce = torch.nn.functional.binary_cross_entropy_with_logits
+        loss = torch.zeros((), dtype=torch.float32, device=g.device)
+        for i in range(self.loss_from, self.num_iter):  # (:439-442)
+            loss = loss + bce(llr_hat[2 * i + 2].t(), gt_x) + bce(llr_hat[2 * i + 3].t(), gt_z)
+        s_hat, ls_hat, _ = g.residual(ex, ez, x_hat.to(torch.uint8).contiguous(), z_hat.to(torch.uint8).contiguous())
+        return s_hat, ls_hat, loss
+
+    call = __call__

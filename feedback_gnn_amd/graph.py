@@ -200,6 +200,12 @@ class TannerGraph:
                                           _stream(self.device)))
         return ex, ez
 
+    def pauli_noise_wt(self, seed, wt, first_sample, B):
+        ex = self._new((B, self.n), torch.uint8)
+        ez = self._new((B, self.n), torch.uint8)
+        check(_lib.lib().fgnn_pauli_noise_wt(int(seed), int(wt), int(first_sample), B, self.n, _ptr(ex), _ptr(ez), _stream(self.device)))
+        return ex, ez
+
     def syndrome(self, ex, ez):
         B = int(ex.shape[0])
         ex = self._chk(ex, (B, self.n), torch.uint8, "noise_x")

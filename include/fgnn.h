@@ -113,6 +113,9 @@ int fgnn_feedback_gnn(const fgnn_graph* g, const fgnn_weights* w, const float* l
  * (feedback_gnn.py:298): Philox4x32-10 stream keyed by (seed, first_sample + b). */
 int fgnn_pauli_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, uint8_t* noise_x, uint8_t* noise_z,
                      void* stream);
+/* Pauli.call with wt=True, pauli.py:80-97 (training-set harvesting, Generate_dataset.ipynb): exactly `wt` qubits per sample
+ * carry an error, X / Y / Z with probability 1/3 each; positions by a Philox-driven partial Fisher-Yates shuffle. */
+int fgnn_pauli_noise_wt(uint64_t seed, int wt, uint64_t first_sample, int B, int n, uint8_t* noise_x, uint8_t* noise_z, void* stream);
 /* syndrome_x = hx noise_z, syndrome_z = hz noise_x (mod 2), feedback_gnn.py:305-309. */
 int fgnn_syndrome(const fgnn_graph* g, const uint8_t* noise_x, const uint8_t* noise_z, int B, uint8_t* synd_x,
                   uint8_t* synd_z, void* stream);

@@ -495,6 +495,38 @@ int og_pauli_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, 
     return 0;
 }
 
+/* Pauli.call with wt=True (pauli.py:80-97): exactly `wt` qubits carry an error, X/Y/Z equiprobable. */
+int og_pauli_noise_wt(uint64_t seed, int wt, uint64_t first_sample, int B, int n, uint8_t* noise_x, uint8_t* noise_z)
+{
+    if (wt < 0 || wt > n) return -1;
+#pragma omp parallel
+    {
+        int* perm = (int*)malloc(sizeof(int) * (size_t)n);
+#pragma omp for schedule(static)
+        for (int b = 0; b < B; ++b) {
+            uint8_t* ex = noise_x + (size_t)b * n;
+            uint8_t* ez = noise_z + (size_t)b * n;
+            memset(ex, 0, (size_t)n);
+            memset(ez, 0, (size_t)n);
+            for (int v = 0; v < n; ++v) perm[v] = v;
+            float up[4] = {0, 0, 0, 0}, ut[4] = {0, 0, 0, 0};
+            for (int i = 0; i < wt; ++i) {
+                if ((i & 3) == 0) {
+                    fg_uniform4s(seed, first_sample + (uint64_t)b, (uint32_t)(i >> 2), 1u, up);
+                    fg_uniform4s(seed, first_sample + (uint64_t)b, (uint32_t)(i >> 2), 2u, ut);
+                }
+                const int j = i + fg_fy_pick(up[i & 3], n - i);
+                const int t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+                const float u = ut[i & 3];
+                ex[perm[i]] = (uint8_t)(u < (2.0f / 3.0f));
+                ez[perm[i]] = (uint8_t)(u > (1.0f / 3.0f));
+            }
+        }
+        free(perm);
+    }
+    return 0;
+}
+
 /* y[b, r] = (A x[b,:]) mod 2 for a CSR binary matrix (int_mod_2(tf.matmul(...)), feedback_gnn.py:308-309). */
 static void spmv2(const int* ptr, const int* col, int rows, const uint8_t* x, uint8_t* y)
 {

@@ -51,6 +51,7 @@ def lib():
         _lib.og_bp2_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib.og_bsc_noise.argtypes = [C.c_uint64, C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
         _lib.og_osd0.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        _lib.og_pauli_noise_wt.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib.og_gnn_bp4.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5
     return _lib
 
@@ -269,3 +270,10 @@ class OracleGraph:
                            0 if idx is None else len(idx), _p(e_hat))
         assert rc == 0
         return e_hat
+
+    def pauli_noise_wt(self, seed, wt, first_sample, B):
+        ex = np.empty((B, self.n), np.uint8)
+        ez = np.empty((B, self.n), np.uint8)
+        rc = lib().og_pauli_noise_wt(int(seed), int(wt), int(first_sample), B, self.n, _p(ex), _p(ez))
+        assert rc == 0
+        return ex, ez
