@@ -155,12 +155,18 @@ def main():
         alg_bytes = algorithmic_bytes_per_codeword(n, m, E, iters[0]) * B
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
+        valu = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 key = f"bp4_{args.code}_it{iters[0]}_B{B}"
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                vi = tj.get(key, {}).get("valu_wave_insts_per_launch")
+                if vi:
+                    # the kernel's true limiter: VALU issue.  1024 SIMDs, 2 cycles per wave64 instruction, 2.4 GHz peak clock
+                    # (the chip holds ~2.34 GHz on this kernel, so this understates the utilisation slightly)
+                    valu = {"wave_insts_per_launch": vi, "issue_utilisation_at_2.4GHz": vi * 2 / (1024 * dom_ms * 1e-3 * 2.4e9)}
             except Exception:
                 traffic = None
         info = g.info()
@@ -179,7 +185,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": f"bp4_kernel<boxplus-phi>, {iters[0]} iterations, B={B}",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": dom_ms, "launches_timed": len(dom),
-                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
                          "note": "messages stay in LDS for all iterations: `achieved` is the reference's streaming-model "
                                  "bytes / kernel time (effective bandwidth); the kernel itself is VALU-issue bound "
                                  "(DESIGN.md §4), `traffic` = HBM bytes actually moved per launch (rocprofv3 PMC)"},
