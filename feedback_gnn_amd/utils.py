@@ -21,7 +21,13 @@ def allreduce_counts(counts):
     """Sum a small integer tensor over all ranks (no-op without an initialised process group)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        if counts.is_cuda and dist.get_backend() != "nccl":
+            # host-memory backends (gloo: CPU tests, or several ranks sharing one GPU) reduce through a CPU copy
+            host = counts.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            counts.copy_(host)
+        else:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     return counts
 
 
