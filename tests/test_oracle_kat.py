@@ -172,3 +172,30 @@ def test_gnn_bp4_oracle_vs_numpy_restatement(name):
     agree = (o["x_hat"] == r["x_hat"]).mean()
     assert agree > 0.98  # random weights leave many marginals near ties; exact ties may break either way
     assert o["x_logit_all"].shape == (4, 12, g.m_z + g.rows_lz)
+
+
+def test_torch_float64_restatement_matches_oracle_forward():
+    """oracle/torch_ref.py (float64, autograd-ready) vs the C oracle on a well-conditioned case: per-iteration soft
+    syndromes and the GNN output agree to float32 accuracy."""
+    import torch
+    from oracle import torch_ref as T
+    name = "gb48"
+    c = code(name)
+    g = oracle_graph(name)
+    ex, ez = g.pauli_noise(SEED, 0.05, 0, 6)
+    sx, sz = g.syndrome(ex, ez)
+    rng = np.random.RandomState(1)
+    llr = rng.uniform(0.5, 2.5, size=(6, 3, c.N)).astype(np.float32)
+    tg = T.Graph(c)
+    xs, zs, _ = T.bp4_logit_trace(tg, torch.from_numpy(llr).to(T.DT), torch.from_numpy(sx), torch.from_numpy(sz), 4, factor=0.9)
+    for it in range(5):
+        o = g.bp4_decode(sx, sz, it, "boxplus-phi", 0.9, llr_ch=llr)
+        assert np.abs(o["x_logit"] - xs[it].numpy()).max() < 2e-4, it
+        assert np.abs(o["z_logit"] - zs[it].numpy()).max() < 2e-4, it
+    w = read_weight_list(WEIGHTS_882)  # architecture only; gb48 has the same feature widths
+    o = g.bp4_decode(sx, sz, 3, "boxplus-phi", 1.0, llr_ch=llr)
+    ref = g.feedback_gnn(w, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
+    tw = [torch.from_numpy(a).to(T.DT) for a in w]
+    out = T.feedback_gnn(tg, tw, torch.from_numpy(o["llr"]).to(T.DT), torch.from_numpy(o["z_logit"]).to(T.DT),
+                         torch.from_numpy(o["x_logit"]).to(T.DT), torch.from_numpy(sx), torch.from_numpy(sz))
+    assert np.abs(ref - out.numpy()).max() < 1e-4
