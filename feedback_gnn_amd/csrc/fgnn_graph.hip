@@ -220,6 +220,24 @@ extern "C" int fgnn_graph_set_rows(fgnn_graph* g, int which, int rows, int nnz, 
     g->d.rows[which] = rows;
     g->d.rptr[which] = static_cast<const int*>(dp);
     g->d.rcol[which] = static_cast<const int*>(dc);
+    if (which < 2) {  // column-major copy for the backward pass
+        const int n = g->d.n;
+        std::vector<int> tp(n + 1, 0), tr(std::max<size_t>(c.size(), 1), 0);
+        for (int x : c) tp[x + 1]++;
+        for (int v = 0; v < n; ++v) tp[v + 1] += tp[v];
+        std::vector<int> fill(tp.begin(), tp.end() - 1);
+        for (int r = 0; r < rows; ++r)
+            for (int p = ptr[r]; p < ptr[r + 1]; ++p) tr[fill[c[p]]++] = r;
+        void *tpd = nullptr, *trd = nullptr;
+        FGNN_HIP_CHECK(hipMalloc(&tpd, tp.size() * sizeof(int)));
+        g->row_alloc[which][2] = tpd;
+        FGNN_HIP_CHECK(hipMalloc(&trd, tr.size() * sizeof(int)));
+        g->row_alloc[which][3] = trd;
+        FGNN_HIP_CHECK(hipMemcpy(tpd, tp.data(), tp.size() * sizeof(int), hipMemcpyHostToDevice));
+        FGNN_HIP_CHECK(hipMemcpy(trd, tr.data(), tr.size() * sizeof(int), hipMemcpyHostToDevice));
+        g->d.tptr[which] = static_cast<const int*>(tpd);
+        g->d.trow[which] = static_cast<const int*>(trd);
+    }
     return FGNN_OK;
 }
 

@@ -23,6 +23,10 @@ struct GraphDev {
     int rows[6];
     const int* rptr[6];
     const int* rcol[6];
+    // column-major view of the two soft-syndrome row sets (which = 0, 1): rows containing qubit v, ascending; used by
+    // the backward kernel to gather row gradients per qubit in a fixed order
+    const int* tptr[2];  // [n+1]
+    const int* trow[2];  // [nnz]
     // uniform degrees, 0 if irregular
     int dvx, dvz, dc;
 };
@@ -37,7 +41,7 @@ struct fgnn_graph {
     std::vector<void*> allocs;
     // host copies of the canonical edge lists (fgnn_graph_edges)
     std::vector<int32_t> h_chk[2], h_var[2];
-    void* row_alloc[6][2];
+    void* row_alloc[6][4];
     void* basis_dev[2] = {nullptr, nullptr};  // pivot rows of hx / hz (fgnn_graph_set_basis, OSD)
     int basis_rank[2] = {0, 0};
     // optional per-launch timing of the BP4 kernel with HIP events on the launch stream (fgnn_profile_*)

@@ -192,6 +192,71 @@ class TannerGraph:
                                            _ptr(synd_x), _ptr(synd_z), B, _ptr(out), _stream(self.device)))
         return out
 
+    # ---- reverse pass of the second training stage (Second_Stage_GNN_BP_Model + tf.GradientTape) ----------
+    def bp4_logit_trace(self, llr_ch, synd_x, synd_z, num_iter, factor=1.0):
+        """Forward of the stage_two decoder with a tape: T chained one-iteration launches.  Returns
+        dict(tape_x [T+1,B,E_x], tape_z [T+1,B,E_z], x_logit [T+1,B,rows0], z_logit [T+1,B,rows1], x_hat, z_hat, llr)."""
+        B, T = int(llr_ch.shape[0]), int(num_iter)
+        tx = torch.zeros((T + 1, B, self.E_x), dtype=torch.float32, device=self.device)
+        tz = torch.zeros((T + 1, B, self.E_z), dtype=torch.float32, device=self.device)
+        xl = self._new((T + 1, B, self.rows_xp), torch.float32)
+        zl = self._new((T + 1, B, self.rows_zp), torch.float32)
+        out = self.bp4_decode(synd_x, synd_z, 0, "boxplus-phi", factor, llr_ch=llr_ch)
+        xl[0], zl[0] = out["x_logit"], out["z_logit"]
+        for k in range(T):
+            out = self.bp4_decode(synd_x, synd_z, 1, "boxplus-phi", factor, llr_ch=llr_ch, msg_init=(tx[k], tz[k]),
+                                  return_msgs=True)
+            tx[k + 1], tz[k + 1] = out["msg_x"], out["msg_z"]
+            xl[k + 1], zl[k + 1] = out["x_logit"], out["z_logit"]
+        return dict(tape_x=tx, tape_z=tz, x_logit=xl, z_logit=zl, x_hat=out["x_hat"], z_hat=out["z_hat"], llr=out["llr"])
+
+    def bp4_backward(self, llr_ch, synd_x, synd_z, tape_x, tape_z, grad_x_logit, grad_z_logit, factor=1.0):
+        """d loss / d llr_ch [B,3,n] from d loss / d soft syndromes [T+1,B,rows] (fgnn_bp4_backward)."""
+        T, B = int(tape_x.shape[0]) - 1, int(llr_ch.shape[0])
+        llr_ch = self._chk(llr_ch, (B, 3, self.n), torch.float32, "llr_ch")
+        synd_x = self._chk(synd_x, (B, self.m_x), torch.uint8, "synd_x")
+        synd_z = self._chk(synd_z, (B, self.m_z), torch.uint8, "synd_z")
+        tape_x = self._chk(tape_x, (T + 1, B, self.E_x), torch.float32, "tape_x")
+        tape_z = self._chk(tape_z, (T + 1, B, self.E_z), torch.float32, "tape_z")
+        gx = self._chk(grad_x_logit, (T + 1, B, self.rows_xp), torch.float32, "grad_x_logit")
+        gz = self._chk(grad_z_logit, (T + 1, B, self.rows_zp), torch.float32, "grad_z_logit")
+        has = ((gx != 0).flatten(1).any(1) | (gz != 0).flatten(1).any(1)).to(torch.uint8).contiguous()
+        out = self._new((B, 3, self.n), torch.float32)
+        check(_lib.lib().fgnn_bp4_backward(self.handle, T, float(factor), _ptr(llr_ch), _ptr(synd_x), _ptr(synd_z), B,
+                                           _ptr(tape_x), _ptr(tape_z), _ptr(gx), _ptr(gz), _ptr(has), _ptr(out),
+                                           _stream(self.device)))
+        return out
+
+    def feedback_gnn_backward(self, weights, llr, logit_hx, logit_hz, synd_x, synd_z, grad_out):
+        """Weight gradients (12 tensors, Keras order) of sum(grad_out * Feedback_GNN(...)): the HIP kernel leaves the
+        (activation, delta) pairs of the four Dense layers in HBM, the reductions over batch x edges are library GEMMs."""
+        B = int(llr.shape[0])
+        llr = self._chk(llr, (B, 3, self.n), torch.float32, "llr")
+        logit_hx = self._chk(logit_hx, (B, self.m_x), torch.float32, "logit_hx")
+        logit_hz = self._chk(logit_hz, (B, self.m_z), torch.float32, "logit_hz")
+        synd_x = self._chk(synd_x, (B, self.m_x), torch.uint8, "synd_x")
+        synd_z = self._chk(synd_z, (B, self.m_z), torch.uint8, "synd_z")
+        grad_out = self._chk(grad_out, (B, 3, self.n), torch.float32, "grad_out")
+        node_in = self._new((B * self.n, 44), torch.float32)
+        node_h2 = self._new((B * self.n, 40), torch.float32)
+        node_d2 = self._new((B * self.n, 40), torch.float32)
+        Es = (self.E_x, self.E_z)
+        feat = [self._new((B * e, 4), torch.float32) for e in Es]
+        h1 = [self._new((B * e, 40), torch.float32) for e in Es]
+        d1 = [self._new((B * e, 40), torch.float32) for e in Es]
+        dm = [self._new((B * e, 20), torch.float32) for e in Es]
+        pp = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])  # noqa: E731
+        check(_lib.lib().fgnn_feedback_gnn_backward(self.handle, weights.handle, _ptr(llr), _ptr(logit_hx), _ptr(logit_hz),
+                                                    _ptr(synd_x), _ptr(synd_z), B, _ptr(grad_out), _ptr(node_in),
+                                                    _ptr(node_h2), _ptr(node_d2), pp(feat), pp(h1), pp(d1), pp(dm),
+                                                    _stream(self.device)))
+        G = grad_out.permute(0, 2, 1).reshape(B * self.n, 3)
+        grads = [node_h2.t() @ G, G.sum(0)]
+        for s in range(2):
+            grads += [feat[s].t() @ d1[s], d1[s].sum(0), h1[s].t() @ dm[s], dm[s].sum(0)]
+        grads += [node_in[:, :43].t() @ node_d2, node_d2.sum(0)]
+        return grads
+
     # ---- channel / syndromes / flags / residual ---------------------------------------------------------
     def pauli_noise(self, seed, p, first_sample, B):
         ex = self._new((B, self.n), torch.uint8)

@@ -189,6 +189,31 @@ int fgnn_gnnbp4_decode(const fgnn_graph* g, const fgnn_gnnbp4_weights* w, int nu
                        const uint8_t* synd_z, int B, uint8_t* x_hat, uint8_t* z_hat, float* llr_out, float* x_logit_all,
                        float* z_logit_all, void* workspace, size_t ws_bytes, void* stream);
 
+/* ---- training: reverse pass of Second_Stage_GNN_BP_Model (feedback_gnn.py:423-463, train_n882.ipynb cell 7) -------------
+ * The reference differentiates GNN -> 16 BP4 iterations (boxplus-phi, stage_two soft syndromes per iteration,
+ * decoding_q.py:768-775) -> BCE with tf.GradientTape.  The two entry points below are that chain rule by hand.
+ *
+ * fgnn_bp4_backward: tape_x/tape_z [T+1,B,E_s] are the c->v messages before iteration k (k = T: after the last one), i.e.
+ * the msg_out of T chained one-iteration fgnn_bp4_decode calls, slot 0 all zero.  grad_x_logit [T+1,B,rows0] /
+ * grad_z_logit [T+1,B,rows1] are d loss / d (soft syndromes after k iterations) (either may be NULL); has_grad [T+1]
+ * (device, u8) flags the k at which a gradient enters.  Output grad_llr_ch [B,3,n] = d loss / d llr_ch.  */
+int fgnn_bp4_backward(const fgnn_graph* g, int num_iter, float normalization_factor, const float* llr_ch,
+                      const uint8_t* synd_x, const uint8_t* synd_z, int B, const float* tape_x, const float* tape_z,
+                      const float* grad_x_logit, const float* grad_z_logit, const uint8_t* has_grad, float* grad_llr_ch,
+                      void* stream);
+
+/* fgnn_feedback_gnn_backward: inputs as fgnn_feedback_gnn plus grad_out [B,3,n] = d loss / d (GNN output).  Leaves the
+ * (activation, delta) pair of every Dense layer in device memory — node_in [B,n,44] (= [mean_x|mean_z|X,Y,Z|0]),
+ * node_h2 / node_d2 [B,n,40], and per side s (0 = hx, 1 = hz) edge_feat[s] [B,E_s,4], edge_h1[s] / edge_d1[s] [B,E_s,40],
+ * edge_dm[s] [B,E_s,20] — so that each weight gradient is one plain GEMM activation^T * delta and each bias gradient a
+ * column sum (Keras order of get_weights(): Wout = node_h2^T G, We = node_in[:, :43]^T node_d2, W1_s = edge_feat^T edge_d1,
+ * W2_s = edge_h1^T edge_dm). */
+int fgnn_feedback_gnn_backward(const fgnn_graph* g, const fgnn_weights* w, const float* llr, const float* logit_hx,
+                               const float* logit_hz, const uint8_t* synd_x, const uint8_t* synd_z, int B,
+                               const float* grad_out, float* node_in, float* node_h2, float* node_d2,
+                               float* const edge_feat[2], float* const edge_h1[2], float* const edge_d1[2],
+                               float* const edge_dm[2], void* stream);
+
 #ifdef __cplusplus
 }
 #endif

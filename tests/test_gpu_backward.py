@@ -1,0 +1,106 @@
+"""Reverse pass of the second training stage (fgnn_bp4_backward, fgnn_feedback_gnn_backward) against autograd of the float64
+restatement oracle/torch_ref.py, i.e. the chain rule tf.GradientTape applies to Second_Stage_GNN_BP_Model.call
+(/root/reference sionna/fec/ldpc/feedback_gnn.py:423-463).  Gradients are float32 on the GPU and float64 in the checker;
+the tolerances below are relative to the gradient's largest entry."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import WEIGHTS_882, code, gpu_graph, to_gpu
+from feedback_gnn_amd.weights_io import read_weight_list
+
+pytestmark = pytest.mark.gpu
+SEED = 20240607
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def _case(name, B, p, lo, hi, seed=3):
+    g = gpu_graph(name)
+    ex, ez = g.pauli_noise(SEED, p, 0, B)
+    sx, sz = g.syndrome(ex, ez)
+    rng = np.random.RandomState(seed)
+    llr = rng.uniform(lo, hi, size=(B, 3, g.n)).astype(np.float32)
+    return g, sx, sz, llr
+
+
+def _bce_grads(g, tr, sx, sz, loss_from, T):
+    """d loss / d soft syndromes by torch autograd on the GPU's own float32 logits (BCE is host-framework work)."""
+    xl = tr["x_logit"].clone().requires_grad_(True)
+    zl = tr["z_logit"].clone().requires_grad_(True)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    gt_x, gt_z = (1 - sz).float(), (1 - sx).float()
+    loss = sum(bce(xl[i + 1], gt_x) + bce(zl[i + 1], gt_z) for i in range(loss_from, T))
+    loss.backward()
+    return loss.item(), xl.grad, zl.grad
+
+
+@pytest.mark.parametrize("name,T,loss_from,factor", [("gb48", 4, 0, 0.9), ("rsurf5", 6, 2, 1.0), ("ghp882", 16, 8, 1.0),
+                                                     ("hp_c7", 5, 0, 0.8)])
+def test_bp4_backward_matches_float64_autograd(name, T, loss_from, factor):
+    from oracle import torch_ref as R
+    B = 4
+    g, sx, sz, llr = _case(name, B, 0.03, 0.8, 2.5)
+    d_llr = to_gpu(llr)
+    tr = g.bp4_logit_trace(d_llr, sx, sz, T, factor)
+    loss, gx, gz = _bce_grads(g, tr, sx, sz, loss_from, T)
+    got = g.bp4_backward(d_llr, sx, sz, tr["tape_x"], tr["tape_z"], gx, gz, factor).cpu().numpy()
+
+    tg = R.Graph(code(name))
+    L = torch.from_numpy(llr).to(R.DT).requires_grad_(True)
+    xs, zs, _ = R.bp4_logit_trace(tg, L, sx.cpu(), sz.cpu(), T, factor)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    gt_x, gt_z = (1 - sz.cpu()).to(R.DT), (1 - sx.cpu()).to(R.DT)
+    ref_loss = sum(bce(xs[i + 1], gt_x) + bce(zs[i + 1], gt_z) for i in range(loss_from, T))
+    ref_loss.backward()
+    assert abs(loss - ref_loss.item()) < 2e-4 * max(1.0, abs(ref_loss.item()))
+    assert np.isfinite(got).all()
+    assert _rel(got, L.grad.numpy()) < 2e-3, _rel(got, L.grad.numpy())
+
+
+def test_bp4_backward_zero_iterations_and_missing_side():
+    """T = 0: only the soft syndromes of the channel LLRs; a NULL gradient for one side contributes nothing."""
+    from oracle import torch_ref as R
+    name = "gb48"
+    g, sx, sz, llr = _case(name, 3, 0.05, -1.0, 3.0)
+    d_llr = to_gpu(llr)
+    tr = g.bp4_logit_trace(d_llr, sx, sz, 0, 1.0)
+    gx = torch.randn_like(tr["x_logit"])
+    gz = torch.zeros_like(tr["z_logit"])
+    got = g.bp4_backward(d_llr, sx, sz, tr["tape_x"], tr["tape_z"], gx, gz).cpu().numpy()
+    tg = R.Graph(code(name))
+    L = torch.from_numpy(llr).to(R.DT).requires_grad_(True)
+    xs, zs, _ = R.bp4_logit_trace(tg, L, sx.cpu(), sz.cpu(), 0, 1.0)
+    (xs[0] * gx[0].cpu().to(R.DT)).sum().backward()
+    assert _rel(got, L.grad.numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["gb48", "ghp882", "rsurf5"])
+def test_feedback_gnn_backward_matches_float64_autograd(name):
+    from oracle import torch_ref as R
+    from feedback_gnn_amd.graph import GnnWeights
+    B = 3
+    g, sx, sz, llr = _case(name, B, 0.04, -2.0, 6.0)
+    rng = np.random.RandomState(5)
+    w = read_weight_list(WEIGHTS_882)
+    w[0] = rng.uniform(-0.4, 0.4, size=w[0].shape).astype(np.float32)  # make every layer matter
+    lhx = rng.uniform(-8, 8, size=(B, g.m_x)).astype(np.float32)
+    lhz = rng.uniform(-8, 8, size=(B, g.m_z)).astype(np.float32)
+    gout = rng.normal(size=(B, 3, g.n)).astype(np.float32)
+    W = GnnWeights(w, g.device)
+    fwd = g.feedback_gnn(W, to_gpu(llr), to_gpu(lhx), to_gpu(lhz), sx, sz)
+    grads = g.feedback_gnn_backward(W, to_gpu(llr), to_gpu(lhx), to_gpu(lhz), sx, sz, to_gpu(gout))
+
+    tg = R.Graph(code(name))
+    tw = [torch.from_numpy(a).to(R.DT).requires_grad_(True) for a in w]
+    out = R.feedback_gnn(tg, tw, torch.from_numpy(llr).to(R.DT), torch.from_numpy(lhx).to(R.DT), torch.from_numpy(lhz).to(R.DT),
+                         sx.cpu(), sz.cpu())
+    assert np.abs(fwd.cpu().numpy() - out.detach().numpy()).max() < 1e-4
+    (out * torch.from_numpy(gout).to(R.DT)).sum().backward()
+    assert len(grads) == 12
+    for i, (got, ref) in enumerate(zip(grads, tw)):
+        assert tuple(got.shape) == tuple(ref.shape), i
+        assert _rel(got.cpu().numpy(), ref.grad.numpy()) < 1e-3, (i, _rel(got.cpu().numpy(), ref.grad.numpy()))
