@@ -50,17 +50,36 @@ class Feedback_GNN:
         for shp in _W_SHAPES:
             w.append(np.ones(shp, np.float32) if len(shp) == 1 else _glorot_uniform(rng, shp))
         w[0] = np.zeros(_W_SHAPES[0], np.float32)
-        self._weights = None
+        self._weights = self._vars = self._var_versions = None
         self.set_weights(w)
 
     def get_weights(self):
+        self._sync()
         return [a.copy() for a in self._weights.arrays]
 
     def set_weights(self, weights):
         self._weights = GnnWeights(list(weights), self.graph.device)
+        self._vars = self._var_versions = None
+
+    @property
+    def trainable_weights(self):
+        """The 12 arrays as float32 device tensors in Keras order (Layer.trainable_weights).  An optimizer updates them in
+        place; the device tables of the kernels are rebuilt from them before the next call."""
+        if self._vars is None:
+            self._vars = [torch.from_numpy(a.copy()).to(self.graph.device) for a in self._weights.arrays]
+            self._var_versions = [v._version for v in self._vars]
+        return self._vars
+
+    trainable_variables = trainable_weights
+
+    def _sync(self):
+        if self._vars is not None and [v._version for v in self._vars] != self._var_versions:
+            self._weights = GnnWeights([v.detach().cpu().numpy() for v in self._vars], self.graph.device)
+            self._var_versions = [v._version for v in self._vars]
 
     @property
     def device_weights(self):
+        self._sync()
         return self._weights
 
     def count_params(self):
@@ -83,7 +102,7 @@ class Feedback_GNN:
                 return (t.to(torch.int64) & 1).to(torch.uint8).t().contiguous()
             return t.to(torch.float32).t().contiguous()
 
-        out = g.feedback_gnn(self._weights, llr, cn(logit_hx, g.m_x, torch.float32), cn(logit_hz, g.m_z, torch.float32),
+        out = g.feedback_gnn(self.device_weights, llr, cn(logit_hx, g.m_x, torch.float32), cn(logit_hz, g.m_z, torch.float32),
                              cn(syndrome_x, g.m_x, torch.uint8), cn(syndrome_z, g.m_z, torch.uint8))
         return out.permute(0, 2, 1).contiguous()
 
@@ -231,20 +250,33 @@ class First_Stage_BP_Model:
 
 
 class Second_Stage_GNN_BP_Model:
-    """Forward pass of the training objective (feedback_gnn.py:395-463): GNN → BP with per-iteration soft syndromes →
+    """The training objective (feedback_gnn.py:395-463): GNN → BP with per-iteration soft syndromes →
     ``loss = sum_{i=loss_from}^{num_iter-1} BCE(1-syndrome_z, x_logit_i) + BCE(1-syndrome_x, z_logit_i)`` plus the residual
-    check.  ``model(noise_x, noise_z, h_vn, logit_hx_perp, logit_hz_perp)`` → ``(s_hat, ls_hat, loss)``.  The loss is a value
-    only: the kernels have no backward pass yet, so this class evaluates and monitors training
-    objectives but cannot update ``feedback``."""
+    check.  ``model(noise_x, noise_z, h_vn, logit_hx_perp, logit_hz_perp)`` → ``(s_hat, ls_hat, loss)``.
+
+    The reference obtains the weight gradients with ``tf.GradientTape`` around this call; here
+    ``model.value_and_grad(...)`` → ``(s_hat, ls_hat, loss, grads)`` runs the hand-written reverse pass
+    (fgnn_bp4_backward, fgnn_feedback_gnn_backward) and returns the 12 gradients in the order of
+    ``model.trainable_weights`` — see ``feedback_gnn_amd.training`` for the optimizer and the loop of Feedback_GNN.ipynb."""
 
     def __init__(self, code, feedback, decoder, num_iter=16, trainable=True, loss_from=8):
         self.feedback, self.decoder, self.num_iter, self.loss_from, self.trainable = feedback, decoder, int(num_iter), int(loss_from), trainable
 
-    def __call__(self, noise_x, noise_z, h_vn, logit_hx_perp, logit_hz_perp):
+    @property
+    def trainable_weights(self):
+        return self.feedback.trainable_weights if self.trainable else []
+
+    trainable_variables = trainable_weights
+
+    def _inputs(self, noise_x, noise_z, h_vn, logit_hx_perp, logit_hz_perp):
         g = self.decoder.graph
         ex = torch.as_tensor(noise_x, device=g.device).to(torch.uint8).contiguous()
         ez = torch.as_tensor(noise_z, device=g.device).to(torch.uint8).contiguous()
         sx, sz = g.syndrome(ex, ez)
+        return g, ex, ez, sx, sz
+
+    def __call__(self, noise_x, noise_z, h_vn, logit_hx_perp, logit_hz_perp):
+        g, ex, ez, sx, sz = self._inputs(noise_x, noise_z, h_vn, logit_hx_perp, logit_hz_perp)
         new_llr = self.feedback((h_vn, logit_hz_perp, logit_hx_perp, sx.t(), sz.t()))  # the swap of :436
         llr_hat, x_hat, z_hat = self.decoder((new_llr.permute(0, 2, 1).contiguous(), sx.t(), sz.t()))
         gt_x = (1 - sz).to(torch.float32)  # labels flipped for BCE (:431-432)
@@ -257,3 +289,32 @@ class Second_Stage_GNN_BP_Model:
         return s_hat, ls_hat, loss
 
     call = __call__
+
+    def value_and_grad(self, noise_x, noise_z, h_vn, logit_hx_perp, logit_hz_perp):
+        """``(s_hat, ls_hat, loss, grads)``: what ``with tf.GradientTape() as tape: ... = model(...)`` followed by
+        ``tape.gradient(loss, model.trainable_variables)`` yields in Feedback_GNN.ipynb cell 8."""
+        g, ex, ez, sx, sz = self._inputs(noise_x, noise_z, h_vn, logit_hx_perp, logit_hz_perp)
+        dev = g.device
+        llr_in = torch.as_tensor(h_vn, device=dev, dtype=torch.float32).permute(0, 2, 1).contiguous()
+        lhx = torch.as_tensor(logit_hz_perp, device=dev, dtype=torch.float32).t().contiguous()  # rows of hx
+        lhz = torch.as_tensor(logit_hx_perp, device=dev, dtype=torch.float32).t().contiguous()  # rows of hz
+        W = self.feedback.device_weights
+        T, factor = self.num_iter, float(self.decoder.normalization_factor)
+        new_llr = g.feedback_gnn(W, llr_in, lhx, lhz, sx, sz)
+        tr = g.bp4_logit_trace(new_llr, sx, sz, T, factor)
+        xl = tr["x_logit"].clone().requires_grad_(True)
+        zl = tr["z_logit"].clone().requires_grad_(True)
+        gt_x, gt_z = (1 - sz).to(torch.float32), (1 - sx).to(torch.float32)
+        bce = torch.nn.functional.binary_cross_entropy_with_logits
+        loss = torch.zeros((), dtype=torch.float32, device=dev)
+        for i in range(self.loss_from, T):
+            loss = loss + bce(xl[i + 1], gt_x) + bce(zl[i + 1], gt_z)
+        if self.loss_from < T:
+            loss.backward()
+            gx, gz = xl.grad, zl.grad
+        else:
+            gx, gz = torch.zeros_like(xl), torch.zeros_like(zl)
+        d_new = g.bp4_backward(new_llr, sx, sz, tr["tape_x"], tr["tape_z"], gx, gz, factor)
+        grads = g.feedback_gnn_backward(W, llr_in, lhx, lhz, sx, sz, d_new)
+        s_hat, ls_hat, _ = g.residual(ex, ez, tr["x_hat"], tr["z_hat"])
+        return s_hat, ls_hat, loss.detach(), grads

@@ -104,3 +104,75 @@ def test_feedback_gnn_backward_matches_float64_autograd(name):
     for i, (got, ref) in enumerate(zip(grads, tw)):
         assert tuple(got.shape) == tuple(ref.shape), i
         assert _rel(got.cpu().numpy(), ref.grad.numpy()) < 1e-3, (i, _rel(got.cpu().numpy(), ref.grad.numpy()))
+
+
+def test_second_stage_value_and_grad_matches_float64_autograd():
+    """The whole training objective (GNN -> 16 stage_two iterations -> summed BCE, feedback_gnn.py:434-442) through the
+    model class: loss and the 12 weight gradients vs oracle/torch_ref.second_stage_loss."""
+    from oracle import torch_ref as R
+    from feedback_gnn_amd import QLDPCBPDecoder, Feedback_GNN, First_Stage_BP_Model, Second_Stage_GNN_BP_Model
+    name, B = "gb48", 6
+    c = code(name)
+    g = gpu_graph(name)
+    dec1 = QLDPCBPDecoder(code=c, num_iter=8, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True, graph=g)
+    dec2 = QLDPCBPDecoder(code=c, num_iter=6, normalization_factor=0.9, cn_type="boxplus-phi", stage_two=True, graph=g)
+    G = Feedback_GNN(code=c, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean", activation="tanh",
+                     use_bias=True, graph=g)
+    rng = np.random.RandomState(9)
+    w = G.get_weights()
+    w[0] = rng.uniform(-0.05, 0.05, size=w[0].shape).astype(np.float32)  # Keras starts this kernel at zero
+    G.set_weights(w)
+    ex, ez = g.pauli_noise(SEED, 0.04, 0, B)
+    m1 = First_Stage_BP_Model(c, dec1)
+    m2 = Second_Stage_GNN_BP_Model(c, G, dec2, num_iter=6, loss_from=2)
+    h_vn, lx, lz = m1(ex, ez)
+    s_hat, b_hat, loss, grads = m2.value_and_grad(ex, ez, h_vn, lx, lz)
+    s2, b2, loss2 = m2(ex, ez, h_vn, lx, lz)
+    assert torch.equal(s_hat, s2) and torch.equal(b_hat, b2) and abs(float(loss) - float(loss2)) < 1e-6
+
+    sx, sz = g.syndrome(ex, ez)
+    tg = R.Graph(c)
+    tw = [torch.from_numpy(a).to(R.DT).requires_grad_(True) for a in w]
+    ref, _ = R.second_stage_loss(tg, tw, h_vn.permute(0, 2, 1).cpu().to(R.DT), lz.t().cpu().to(R.DT), lx.t().cpu().to(R.DT),
+                                 sx.cpu(), sz.cpu(), num_iter=6, loss_from=2, factor=0.9)
+    ref.backward()
+    assert abs(float(loss) - ref.item()) < 1e-4 * max(1.0, abs(ref.item()))
+    for i, (got, t) in enumerate(zip(grads, tw)):
+        assert _rel(got.cpu().numpy(), t.grad.numpy()) < 5e-3, (i, _rel(got.cpu().numpy(), t.grad.numpy()))
+
+
+def test_adam_step_follows_keras_update_rule():
+    from feedback_gnn_amd.training import Adam
+    v = torch.tensor([1.0, -2.0, 3.0], device="cuda")
+    g = torch.tensor([0.5, -0.25, 0.0], device="cuda")
+    opt = Adam(learning_rate=0.1)
+    ref, m, s = v.cpu().double().clone(), torch.zeros(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64)
+    for t in range(1, 4):
+        opt.apply_gradients([(g, v)])
+        gd = g.cpu().double()
+        m = 0.9 * m + 0.1 * gd
+        s = 0.999 * s + 0.001 * gd * gd
+        ref = ref - 0.1 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (s.sqrt() + 1e-7)
+    assert torch.allclose(v.cpu().double(), ref, atol=1e-6)
+
+
+def test_training_reduces_the_loss_on_a_fixed_set():
+    """A short run of the Feedback_GNN.ipynb loop on harvested BP failures of gb126: the objective goes down."""
+    from feedback_gnn_amd import (QLDPCBPDecoder, Feedback_GNN, Sandwich_BP_GNN_Evaluation_Model, First_Stage_BP_Model,
+                                  Second_Stage_GNN_BP_Model)
+    from feedback_gnn_amd.training import harvest_failures, train_second_stage
+    c = code("gb126")
+    g = gpu_graph("gb126")
+    dec1 = QLDPCBPDecoder(code=c, num_iter=32, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True, graph=g)
+    dec2 = QLDPCBPDecoder(code=c, num_iter=16, normalization_factor=1.0, cn_type="boxplus-phi", stage_two=True, graph=g)
+    G = Feedback_GNN(code=c, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean", activation="tanh",
+                     use_bias=True, graph=g)
+    ev = Sandwich_BP_GNN_Evaluation_Model(c, [dec1], [], num_layers=1)
+    X, Z = harvest_failures(ev, 4096, 0.08, 400)
+    assert X.shape[0] == 400
+    m1, m2 = First_Stage_BP_Model(c, dec1), Second_Stage_GNN_BP_Model(c, G, dec2, num_iter=16)
+    w0 = G.get_weights()
+    hist = np.array(train_second_stage(m1, m2, X, Z, batch_size=100, learning_rate=2e-3, epochs=10, log_every=0))
+    assert np.isfinite(hist).all()
+    assert hist[-8:, 0].mean() < hist[:8, 0].mean() - 0.05, (hist[:8, 0].mean(), hist[-8:, 0].mean())
+    assert any(np.abs(a - b).max() > 1e-4 for a, b in zip(w0, G.get_weights()))
