@@ -114,3 +114,23 @@ def test_shard_range_partitions_exactly():
         assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_training_helpers_on_cpu_tensors():
+    """Adam (Keras update rule), clip_by_value and compute_bler are plain tensor code and run without a GPU."""
+    import torch
+    from feedback_gnn_amd.training import Adam, clip_by_value, compute_bler
+    v = torch.tensor([1.0, -2.0, 3.0])
+    g = torch.tensor([0.5, -0.25, 0.0])
+    opt = Adam(learning_rate=lambda step: 0.1)
+    ref, m, s = v.double().clone(), torch.zeros(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64)
+    for t in range(1, 5):
+        opt.apply_gradients([(g, v), (None, v)])
+        m = 0.9 * m + 0.1 * g.double()
+        s = 0.999 * s + 0.001 * g.double() ** 2
+        ref = ref - 0.1 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (s.sqrt() + 1e-7)
+    assert torch.allclose(v.double(), ref, atol=1e-6) and opt.iterations == 4
+    assert clip_by_value(torch.tensor([-20.0, 3.0, 11.0]), -10, 10).tolist() == [-10.0, 3.0, 10.0]
+    b = torch.zeros((4, 5), dtype=torch.uint8)
+    bh = b.clone(); bh[1, 2] = 1; bh[3, 0] = 1; bh[3, 4] = 1
+    assert compute_bler(b, bh) == 0.5
