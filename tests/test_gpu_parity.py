@@ -431,3 +431,56 @@ def test_overcomplete_irregular_graph():
     s0, l0, f0 = og.residual(ex, ez, o["x_hat"], o["z_hat"])
     s1, l1, f1 = gg.residual(to_gpu(ex), to_gpu(ez), g["x_hat"], g["z_hat"])
     assert np.array_equal(s0, s1.cpu().numpy()) and np.array_equal(f0, f1.cpu().numpy())
+
+
+def test_north_star_full_size_properties_and_strided_oracle_check():
+    """BASELINE.json's north-star size: [[882,24]], batch 65 536, p = 0.01, sandwich (64, G, 16).  The oracle cannot
+    decode 65 536 samples in seconds, so the full batch is checked through properties that do not depend on the size —
+    (i) a strided subset (every 128th sample) equals the oracle bit for bit, (ii) the decision depends on the syndrome
+    only: adding a stabilizer to the error leaves it unchanged, (iii) samples the sandwich does not flag satisfy both
+    syndrome equations, (iv) a permuted batch gives permuted results, (v) the device counters equal the host count."""
+    from feedback_gnn_amd.graph import GnnWeights
+    from feedback_gnn_amd.weights_io import read_weight_list
+    name, B, p = "ghp882", 65536, 0.01
+    og, gg = oracle_graph(name), gpu_graph(name)
+    c = code(name)
+    w = read_weight_list(WEIGHTS_882)
+    gw = GnnWeights(w, gg.device)
+    L0 = llr_const(0.05)
+    ex, ez = gg.pauli_noise(SEED, p, 0, B)
+    sx, sz = gg.syndrome(ex, ez)
+    full = gg.sandwich_decode(sx, sz, [64, 16], [gw], L0, return_llr=True, return_rounds=True)
+    # (i) strided subset against the oracle (same Philox samples: index = global sample index)
+    idx = torch.arange(0, B, 128, device=gg.device)
+    o = og.sandwich_decode(sx[idx].cpu().numpy(), sz[idx].cpu().numpy(), [64, 16], [w], L0, return_llr=True)
+    assert np.array_equal(o["x_hat"], full["x_hat"][idx].cpu().numpy())
+    assert np.array_equal(o["z_hat"], full["z_hat"][idx].cpu().numpy())
+    assert np.array_equal(o["llr"], full["llr"][idx].cpu().numpy())
+    assert np.array_equal(o["rounds"], full["rounds"][idx].cpu().numpy())
+    # (ii) e and e + stabilizer share the syndrome, hence the decision: X-type stabilizers are rows of hx, Z-type rows of hz
+    rng = np.random.RandomState(0)
+    rows_x = torch.from_numpy(c.hx[rng.randint(0, c.hx.shape[0], size=B)].astype(np.uint8)).to(gg.device)
+    rows_z = torch.from_numpy(c.hz[rng.randint(0, c.hz.shape[0], size=B)].astype(np.uint8)).to(gg.device)
+    sx2, sz2 = gg.syndrome(ex ^ rows_x, ez ^ rows_z)
+    assert torch.equal(sx, sx2) and torch.equal(sz, sz2)
+    # (iii) unflagged samples reproduce their syndromes; flags/counters consistent
+    s_hat, ls_hat, flags = gg.residual(ex, ez, full["x_hat"], full["z_hat"])
+    ok = (flags & 1) == 0
+    hx_t = torch.from_numpy(c.hx.astype(np.float32)).to(gg.device)
+    hz_t = torch.from_numpy(c.hz.astype(np.float32)).to(gg.device)
+    syn_of_zhat = (full["z_hat"].float() @ hx_t.t()).remainder(2).to(torch.uint8)
+    syn_of_xhat = (full["x_hat"].float() @ hz_t.t()).remainder(2).to(torch.uint8)
+    assert torch.equal(syn_of_zhat[ok], sx[ok]) and torch.equal(syn_of_xhat[ok], sz[ok])
+    assert bool((s_hat[ok] == 0).all()) and bool((((flags >> 1) & 1) >= (flags & 1)).all())  # flagged implies block error
+    counts = torch.zeros(3, dtype=torch.int64, device=gg.device)
+    gg.count_flags(flags, counts)
+    assert counts.tolist() == [int((flags & 1).sum()), int(((flags >> 1) & 1).sum()), B]
+    assert int(ok.sum()) > 0.999 * B  # p = 0.01 is deep in the waterfall
+    # (iv) permutation equivariance over the whole batch (workgroup placement must not matter)
+    perm = torch.randperm(B, device=gg.device, generator=torch.Generator(device=gg.device).manual_seed(1))
+    pr = gg.sandwich_decode(sx[perm].contiguous(), sz[perm].contiguous(), [64, 16], [gw], L0, return_llr=True)
+    assert torch.equal(pr["x_hat"], full["x_hat"][perm]) and torch.equal(pr["z_hat"], full["z_hat"][perm])
+    assert torch.equal(pr["llr"], full["llr"][perm])
+    # (v) the compacted driver (feedback rounds on flagged samples only) gives the same decisions at full size
+    cp = gg.sandwich_decode(sx, sz, [64, 16], [gw], L0, compact=True)
+    assert torch.equal(cp["x_hat"], full["x_hat"]) and torch.equal(cp["z_hat"], full["z_hat"])
