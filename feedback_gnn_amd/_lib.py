@@ -92,7 +92,7 @@ def lib():
         # brought into the process (same soname), which is what makes torch's device pointers and streams
         # valid inside libfgnn_hip.so.  Loading the library before torch would start a second runtime.
         import torch  # noqa: F401
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(os.environ.get("FGNN_LIB_PATH", LIB_PATH))  # override: A/B builds of the same ABI (tools/)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res
