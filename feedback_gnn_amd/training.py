@@ -54,18 +54,20 @@ class Adam:
                 v.sub_(lr_t * m / (s.sqrt() + self.epsilon))
 
 
-def harvest_failures(model_eval, batch_size, p, count, max_batches=1000):
+def harvest_failures(model_eval, batch_size, p, count, max_batches=1000, on_device=False):
     """Error patterns the evaluation model fails on (examples/Generate_dataset.ipynb): ``(noise_x, noise_z)`` uint8 arrays
-    with ``count`` rows, collected with ``Sandwich_BP_GNN_Evaluation_Model.failures``."""
+    with at most ``count`` rows, collected with ``Sandwich_BP_GNN_Evaluation_Model.failures`` over at most ``max_batches``
+    batches (``p`` is the error weight when the model was built with ``wt=True``)."""
     xs, zs, have = [], [], 0
     for _ in range(max_batches):
         fx, fz = model_eval.failures(batch_size, p)[:2]
-        xs.append(torch.as_tensor(fx).cpu())
-        zs.append(torch.as_tensor(fz).cpu())
+        xs.append(fx if on_device else fx.cpu())
+        zs.append(fz if on_device else fz.cpu())
         have += int(xs[-1].shape[0])
         if have >= count:
             break
-    return torch.cat(xs)[:count].numpy(), torch.cat(zs)[:count].numpy()
+    X, Z = torch.cat(xs)[:count], torch.cat(zs)[:count]
+    return (X, Z) if on_device else (X.numpy(), Z.numpy())
 
 
 def train_second_stage(model_stage_one, model_stage_two, dataset_x, dataset_z, batch_size=100, learning_rate=2e-4,
@@ -74,6 +76,7 @@ def train_second_stage(model_stage_one, model_stage_two, dataset_x, dataset_z, b
     Returns the per-step history ``[(loss, bler, flagged_bler), ...]``; updates ``model_stage_two.feedback`` in place."""
     opt = optimizer if optimizer is not None else Adam(learning_rate)
     N = int(dataset_x.shape[0])
+    on_device = torch.is_tensor(dataset_x)  # datasets may stay in HBM (uint8 [N, n] tensors) or come as NumPy arrays
     rng = np.random.RandomState(seed)
     history, it = [], 0
     steps = epochs * ((N + batch_size - 1) // batch_size)
@@ -81,6 +84,8 @@ def train_second_stage(model_stage_one, model_stage_two, dataset_x, dataset_z, b
         order = rng.permutation(N)  # dataset.shuffle(dataset_size, reshuffle_each_iteration=True)
         for lo in range(0, N, batch_size):
             idx = order[lo:lo + batch_size]
+            if on_device:
+                idx = torch.from_numpy(idx).to(dataset_x.device)
             x, z = dataset_x[idx], dataset_z[idx]
             it += 1
             h_vn, lx, lz = model_stage_one(x, z)

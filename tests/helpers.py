@@ -24,6 +24,17 @@ CODE_MAKERS = {
                        [-1, 0, 5, -1, 106]]), [0, 1, 7], name="GHP_n1270_k28"),
 }
 
+
+
+def _overcomplete(key):
+    """The reference's over-complete GB check matrices (A-list data files, QLDPC.ipynb cell 5) from tests/golden/overcomplete.npz."""
+    g = np.load(os.path.join(GOLDEN, "overcomplete.npz"))
+    return cq.css_code(hx=unpack(g, key, "hx").astype(int), hz=unpack(g, key, "hz").astype(int), name=None, name_prefix="GB")
+
+
+CODE_MAKERS["gb46_oc"] = lambda: _overcomplete("gb46_oc")
+CODE_MAKERS["gb48_oc"] = lambda: _overcomplete("gb48_oc")
+
 WEIGHTS_882 = "feedback_GNN_n882_k24_wt_4_60_iter_64_16_mixed.npz"
 WEIGHTS_1270 = "feedback_GNN_n1270_k28_wt_10_80_iter_64_16_mixed.npz"
 
@@ -52,7 +63,9 @@ def llr_const(p0):
 
 
 def golden_codes():
-    return np.load(os.path.join(GOLDEN, "codes.npz"))
+    out = dict(np.load(os.path.join(GOLDEN, "codes.npz")))
+    out.update(np.load(os.path.join(GOLDEN, "overcomplete.npz")))
+    return out
 
 
 def unpack(g, key, attr):

@@ -1,4 +1,6 @@
 """Host substrate vs the reference's own NumPy code (golden fixtures) and its notebook outputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -74,3 +76,34 @@ def test_small_helpers():
     assert np.array_equal(A, [[5, -1, 7], [7, 5, -1], [-1, 7, 5]])
     lines = [[3, 2], [2, 3], [2, 1, 2], [3, 3], [1, 2], [2, 0], [1, 2], [1, 3, 0], [1, 2, 3]]
     assert cq.alistToNumpy(lines).shape == (2, 3)
+
+
+@pytest.mark.parametrize("key", ["gb46_oc", "gb48_oc"])
+def test_overcomplete_alist_codes_match_reference(key, tmp_path):
+    """QLDPC.ipynb cell 5: css_code on the over-complete matrices of the reference's A-list files (800 x 46 and 2000 x 48,
+    row weights 8-12, column weights up to 258): kernels, logicals and parameters equal the reference's own output, and the
+    A-list reader round-trips the matrix."""
+    import numpy as np
+    from feedback_gnn_amd import codes_q as cq
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "overcomplete.npz"))
+    c = code(key)
+    for attr in ("hx", "hz", "hx_perp", "hz_perp", "lx", "lz"):
+        assert np.array_equal(np.asarray(getattr(c, attr)) % 2, unpack(g, key, attr)), attr
+    N, K, D, L, Q, rx, rz = g[f"{key}/scalars"]
+    assert (c.N, c.K, int(c.D), int(c.L), int(c.Q), c.rank_hx, c.rank_hz) == (N, K, D, L, Q, rx, rz)
+    assert c.name == str(g[f"{key}/name"])
+    assert not np.any(c.hx @ c.hz.T % 2)
+    # A-list text: "ncols nrows" / "max col weight, max row weight" / column weights / row weights / per column the 1-based
+    # row indices padded with 0 / per row the 1-based column indices padded with 0
+    pcm = np.vstack([c.hx, c.hz])
+    cw, rw = pcm.sum(0), pcm.sum(1)
+    lines = [f"{pcm.shape[1]} {pcm.shape[0]}", f"{cw.max()} {rw.max()}", " ".join(map(str, cw)), " ".join(map(str, rw))]
+    for j in range(pcm.shape[1]):
+        idx = list(np.nonzero(pcm[:, j])[0] + 1)
+        lines.append(" ".join(map(str, idx + [0] * (cw.max() - len(idx)))))
+    for i in range(pcm.shape[0]):
+        idx = list(np.nonzero(pcm[i])[0] + 1)
+        lines.append(" ".join(map(str, idx + [0] * (rw.max() - len(idx)))))
+    path = tmp_path / "m.alist"
+    path.write_text("\n".join(lines) + "\n")
+    assert np.array_equal(cq.readAlist(str(path)), pcm)

@@ -484,3 +484,39 @@ def test_north_star_full_size_properties_and_strided_oracle_check():
     # (v) the compacted driver (feedback rounds on flagged samples only) gives the same decisions at full size
     cp = gg.sandwich_decode(sx, sz, [64, 16], [gw], L0, compact=True)
     assert torch.equal(cp["x_hat"], full["x_hat"]) and torch.equal(cp["z_hat"], full["z_hat"])
+
+
+@pytest.mark.parametrize("name", ["gb46_oc", "gb48_oc"])
+@pytest.mark.parametrize("cn_type", ["boxplus-phi", "minsum"])
+def test_reference_overcomplete_codes_bit_exact(name, cn_type):
+    """The reference's over-complete GB matrices (QLDPC.ipynb cell 5; 400+400 / 1000+1000 checks on 46 / 48 qubits, row
+    weights 8-12, column weights up to 258): runtime-degree kernel, 6 iterations as in cell 11, against the oracle."""
+    B = 37
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, 0.08, B)
+    L0 = llr_const(0.3)
+    o = oracle_graph(name).bp4_decode(sx, sz, 6, cn_type, 1.0, llr_const=L0, return_msgs=True)
+    g = gpu_graph(name).bp4_decode(tx, tz, 6, cn_type, 1.0, llr_const=L0, return_msgs=True)
+    _assert_bp_equal(o, g, f"{name} {cn_type}")
+    s0, l0, f0 = oracle_graph(name).residual(ex, ez, o["x_hat"], o["z_hat"])
+    s1, l1, f1 = gpu_graph(name).residual(gx, gz, g["x_hat"], g["z_hat"])
+    assert np.array_equal(s0, s1.cpu().numpy()) and np.array_equal(l0, l1.cpu().numpy()) and np.array_equal(f0, f1.cpu().numpy())
+
+
+@pytest.mark.parametrize("name,p,flagged,block,total", [("gb48_oc", 0.10, 746, 1673, 10000), ("gb48_oc", 0.06, 63, 217, 10000),
+                                                        ("gb46_oc", 0.10, 505, 892, 10000), ("gb46_oc", 0.07, 82, 191, 10000)])
+def test_published_rows_overcomplete_codes(name, p, flagged, block, total):
+    """QLDPC.ipynb cell 12, 'GB_n48_k6_oc / GB_n46_k2_oc, factor=1.0, iterations=6, p0=0.3': flagged and logical error
+    counts of the published rows inside binomial 4-sigma bands (two independent draws), on 4x the published sample count."""
+    from feedback_gnn_amd import QLDPCBPDecoder, Sandwich_BP_GNN_Evaluation_Model
+    c = code(name)
+    dec = QLDPCBPDecoder(code=c, num_iter=6, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True, graph=gpu_graph(name))
+    m = Sandwich_BP_GNN_Evaluation_Model(c, [dec], [], num_layers=1, p0=0.3)
+    counts = torch.zeros(3, dtype=torch.int64, device="cuda")
+    n = 4 * total
+    m.mc_step(n, p, counts)
+    fl, bl, tot = [int(v) for v in counts.cpu()]
+    assert tot == n
+    for got, pub in ((fl, flagged), (bl, block)):
+        r = pub / total
+        sigma = np.sqrt(r * (1 - r) * (1 / total + 1 / n))
+        assert abs(got / n - r) < 4 * sigma + 2 / total, (name, p, got / n, r)
