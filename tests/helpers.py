@@ -16,6 +16,7 @@ CODE_MAKERS = {
     "toric4": lambda: cq.create_checkerboard_toric_codes(4),
     "gb48": lambda: cq.create_generalized_bicycle_codes(24, [0, 2, 8, 15], [0, 2, 12, 17], name="GB_n48_k6_d8"),
     "gb126": lambda: cq.create_generalized_bicycle_codes(63, [0, 1, 14, 16, 22], [0, 3, 13, 20, 42]),
+    "gb254": lambda: cq.create_generalized_bicycle_codes(127, [0, 15, 20, 28, 66], [0, 58, 59, 100, 121]),
     "hp_c7": lambda: cq.hypergraph_product(cq.create_circulant_matrix(7, [0, 1, 3]), cq.create_circulant_matrix(7, [0, 1, 3])),
     "ibm72": lambda: cq.create_bivariate_QC_codes(6, 6, [3], [1, 2], [1, 2], [3]),
     "ghp882": lambda: cq.create_QC_GHP_codes(63, cq.create_cyclic_permuting_matrix(7, [27, 54, 0]), [0, 1, 6]),

@@ -502,15 +502,28 @@ def test_reference_overcomplete_codes_bit_exact(name, cn_type):
     assert np.array_equal(s0, s1.cpu().numpy()) and np.array_equal(l0, l1.cpu().numpy()) and np.array_equal(f0, f1.cpu().numpy())
 
 
-@pytest.mark.parametrize("name,p,flagged,block,total", [("gb48_oc", 0.10, 746, 1673, 10000), ("gb48_oc", 0.06, 63, 217, 10000),
-                                                        ("gb46_oc", 0.10, 505, 892, 10000), ("gb46_oc", 0.07, 82, 191, 10000)])
-def test_published_rows_overcomplete_codes(name, p, flagged, block, total):
-    """QLDPC.ipynb cell 12, 'GB_n48_k6_oc / GB_n46_k2_oc, factor=1.0, iterations=6, p0=0.3': flagged and logical error
-    counts of the published rows inside binomial 4-sigma bands (two independent draws), on 4x the published sample count."""
+PUBLISHED_BP4_ROWS = [
+    # (code, iterations, factor, p0, p, flag errors, block errors, num blocks) — examples/QLDPC.ipynb cell 12
+    ("gb48_oc", 6, 1.0, 0.3, 0.10, 746, 1673, 10000), ("gb48_oc", 6, 1.0, 0.3, 0.06, 63, 217, 10000),
+    ("gb46_oc", 6, 1.0, 0.3, 0.10, 505, 892, 10000), ("gb46_oc", 6, 1.0, 0.3, 0.07, 82, 191, 10000),
+    ("gb254", 64, 0.625, 0.1, 0.09, 2786, 2786, 10000), ("gb254", 64, 0.625, 0.1, 0.07, 425, 425, 10000),
+    ("gb126", 64, 0.8, 0.1, 0.10, 4786, 4829, 10000), ("gb126", 64, 0.8, 0.1, 0.06, 533, 553, 10000),
+    ("ghp882", 64, 0.8, 0.3, 0.10, 4385, 4385, 10000), ("ghp882", 64, 0.8, 0.3, 0.09, 1318, 1318, 10000),
+    ("ghp882", 64, 0.8, 0.3, 0.08, 147, 147, 10000),
+    ("ghp1270", 64, 0.8, 0.3, 0.10, 4813, 4813, 10000), ("ghp1270", 64, 0.8, 0.3, 0.09, 1027, 1027, 10000),
+]
+
+
+@pytest.mark.parametrize("name,iters,factor,p0,p,flagged,block,total", PUBLISHED_BP4_ROWS)
+def test_published_rows_plain_bp4(name, iters, factor, p0, p, flagged, block, total):
+    """QLDPC.ipynb cell 12 (plain flooding BP4, boxplus-phi; the over-complete GB codes, GB_n254, GB_n126 with unflagged
+    logical errors, and both GHP codes at factor 0.8 / p0 = 0.3): flagged and logical error counts of the published rows
+    inside binomial 4-sigma bands (two independent draws), on 4x the published sample count."""
     from feedback_gnn_amd import QLDPCBPDecoder, Sandwich_BP_GNN_Evaluation_Model
     c = code(name)
-    dec = QLDPCBPDecoder(code=c, num_iter=6, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True, graph=gpu_graph(name))
-    m = Sandwich_BP_GNN_Evaluation_Model(c, [dec], [], num_layers=1, p0=0.3)
+    dec = QLDPCBPDecoder(code=c, num_iter=iters, normalization_factor=factor, cn_type="boxplus-phi", stage_one=True,
+                         graph=gpu_graph(name))
+    m = Sandwich_BP_GNN_Evaluation_Model(c, [dec], [], num_layers=1, p0=p0)
     counts = torch.zeros(3, dtype=torch.int64, device="cuda")
     n = 4 * total
     m.mc_step(n, p, counts)
