@@ -222,10 +222,10 @@ def main():
             t_cs = timed(lambda: model_c.mc_step(B, args.p, cc))
             g.set_saturation_shortcut(False)
             out["extras"] = {"bp4_only_cw_per_s (configs[1])": B / t_bp,
-                             "bp4_only_with_saturation_shortcut_cw_per_s (product default, identical outputs)": B / t_bp_s,
-                             "sandwich_with_saturation_shortcut_cw_per_s (product default, identical outputs)": B / t_s,
+                             "bp4_only_product_default_cw_per_s (exact saturation shortcut + fixed-point exit, identical outputs)": B / t_bp_s,
+                             "sandwich_product_default_cw_per_s (exact saturation shortcut + fixed-point exit, identical outputs)": B / t_s,
                              "sandwich_compacted_cw_per_s (feedback rounds only on flagged samples, same outputs)": B / t_c,
-                             "sandwich_compacted_with_saturation_shortcut_cw_per_s (both exact optimisations, same outputs)": B / t_cs}
+                             "sandwich_compacted_product_default_cw_per_s (all exact optimisations, same outputs)": B / t_cs}
         if args.cpu_sample != 0:
             from feedback_gnn_amd.weights_io import read_weight_list
             from oracle.oracle import OracleGraph, num_threads

@@ -40,6 +40,8 @@ struct BpArgs {
     float* msg_out_z;
     const int* index;         // optional: workgroup slot -> sample (compacted rounds of the sandwich driver)
     int shortcut;             // 1: wave-uniform exact shortcuts for saturated nodes (regular kernel)
+    int early_exit;           // 1: leave the iteration loop at a proven fixed point (needs shortcut, cpb == 1, phi rule)
+    int sig_off;              // float offset of the fixed-point detector's LDS words (n sign words + 4 flags)
 };
 
 __device__ __forceinline__ unsigned sign_bit(float x) { return fg_f2u(x) >> 31; }
@@ -140,7 +142,7 @@ __device__ __forceinline__ float logit_row(const float* llr, const int* __restri
 // c->v update of one (DC-regular) check with every message in registers: the phi rule of the benchmark
 // configurations without the LDS round trip of the runtime-degree version.  Same float ops, same order.
 template <int DC>
-__device__ __forceinline__ void cn_phi_regular(float* msg, const int (&sl)[DC], unsigned synd, float factor, float phi0,
+__device__ __forceinline__ bool cn_phi_regular(float* msg, const int (&sl)[DC], unsigned synd, float factor, float phi0,
                                                bool shortcut)
 {
     float v[DC], aa[DC];
@@ -160,7 +162,7 @@ __device__ __forceinline__ void cn_phi_regular(float* msg, const int (&sl)[DC], 
     if (shortcut && __all(sat)) {
 #pragma unroll
         for (int j = 0; j < DC; ++j) msg[sl[j]] = with_sign(phi0, neg ^ ng[j]) * factor;
-        return;
+        return true;
     }
     float T = 0.0f;
 #pragma unroll
@@ -173,6 +175,7 @@ __device__ __forceinline__ void cn_phi_regular(float* msg, const int (&sl)[DC], 
         const float out = fg_phi(T - aa[j]);
         msg[sl[j]] = with_sign(out, neg ^ ng[j]) * factor;
     }
+    return false;
 }
 
 // tf2xla softplus for |t| > 13.94 only: identity above, exp(t) below (flushed under -87); same bits as fg_softplus there.
@@ -213,7 +216,20 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
 
     const float phi0 = fg_phi(0.0f);  // = phi(clip min) = 16.6355324, the saturated message magnitude
     (void)phi0;
+    // Fixed-point detector (exact early exit, regular phi kernel, one codeword per block).  If the check-node phases of
+    // iterations t-1 and t-2 were all-shortcut, every c->v message entering iterations t-1 and t has the same magnitude
+    // phi0*factor, so "the sign words of iteration t equal those of iteration t-1" means mu^t == mu^(t-1) bit for bit; the
+    // iteration map is deterministic, hence mu^(t+1) == mu^t and every later iteration is the identity.
+    unsigned* sigw = reinterpret_cast<unsigned*>(msg + a.sig_off);  // [n] sign words, then 2 x {changed, cn_slow}
+    int* flags = reinterpret_cast<int*>(sigw + n);
+    bool a1 = false, a2 = false;
+    if (a.early_exit) {
+        for (int v = lane; v < n; v += a.tpc) sigw[v] = 0xffffffffu;
+        if (lane < 4) flags[lane] = 0;
+        __syncthreads();
+    }
     for (int it = 0; it < a.num_iter; ++it) {
+        bool changed = false, cn_slow = false;
         // ---- variable nodes: _vn_update (:227-275) ----
         if (active)
             for (int v = lane; v < n; v += a.tpc) {
@@ -229,6 +245,17 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
                     for (int k = 0; k < DVZ; ++k) { mz[k] = pz[k]; Sz = Sz + mz[k]; }
 #pragma unroll
                     for (int k = 0; k < DVX; ++k) { mx[k] = px[k]; Sx = Sx + mx[k]; }
+                    if (a.early_exit) {
+                        unsigned sig = 0;
+#pragma unroll
+                        for (int k = 0; k < DVX; ++k) sig |= sign_bit(mx[k]) << k;
+#pragma unroll
+                        for (int k = 0; k < DVZ; ++k) sig |= sign_bit(mz[k]) << (DVX + k);
+                        if (sigw[v] != sig) {
+                            changed = true;
+                            sigw[v] = sig;
+                        }
+                    }
                     const float Y = (Sz + Sx) + ly;
                     const float X = Sz + lx;
                     const float Z = Sx + lz;
@@ -288,8 +315,13 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
                     }
                 }
             }
+        if (a.early_exit && changed) flags[2 * (it & 1)] = 1;
         __syncthreads();
         // ---- check nodes of both graphs (:752-767) ----
+        if (a.early_exit && lane == 0) {  // clear the other parity's flags: nobody reads or sets them during this phase
+            flags[2 * ((it + 1) & 1)] = 0;
+            flags[2 * ((it + 1) & 1) + 1] = 0;
+        }
         if (active)
             for (int c = lane; c < g.m; c += a.tpc) {
                 const unsigned synd = (c < g.m_x ? sx[c] : sz[c - g.m_x]) & 1u;
@@ -299,14 +331,22 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
                     int sl[DC];
 #pragma unroll
                     for (int j = 0; j < DC; ++j) sl[j] = (int)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
-                    if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI) cn_phi_regular<DC>(msg, sl, synd, a.factor, phi0, a.shortcut != 0);
+                    if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI)
+                        cn_slow = !cn_phi_regular<DC>(msg, sl, synd, a.factor, phi0, a.shortcut != 0) || cn_slow;
                     else cn_update<CN_TYPE>(msg, sl, DC, synd, a.factor);
                 } else {
                     const int c0 = g.cptr[c], deg = g.cptr[c + 1] - c0;
                     cn_update<CN_TYPE>(msg, g.cslot + c0, deg, synd, a.factor);
                 }
             }
+        if (a.early_exit && cn_slow) flags[2 * (it & 1) + 1] = 1;
         __syncthreads();
+        if (a.early_exit) {
+            const bool stable = a1 && a2 && flags[2 * (it & 1)] == 0;
+            a2 = a1;
+            a1 = flags[2 * (it & 1) + 1] == 0;
+            if (stable) break;  // block-uniform: every thread reads the same LDS words after the barrier
+        }
     }
 
     // ---- marginals (:777), hard decision (:783-790), binary LLRs of cal_logit (:455-464) ----
@@ -434,6 +474,15 @@ int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float n
     per_cw = (per_cw + 3) & ~3;
     a.lds_per_cw = per_cw;
     size_t lds_bytes = (size_t)per_cw * sizeof(float) * (size_t)L.cpb;
+    const bool regular = g->d.cslot16 && !g->force_generic &&
+                         ((g->d.dvx == 3 && g->d.dvz == 3 && g->d.dc == 6) || (g->d.dvx == 4 && g->d.dvz == 4 && g->d.dc == 8));
+    a.early_exit = (g->shortcut && g->early_exit && regular && cn_type == FGNN_CN_BOXPLUS_PHI && L.cpb == 1 && num_iter > 2) ? 1 : 0;
+    a.sig_off = per_cw;
+    if (a.early_exit) {
+        const size_t with_det = lds_bytes + ((size_t)g->d.n + 4) * sizeof(float);
+        if (with_det <= 160 * 1024) lds_bytes = with_det;
+        else a.early_exit = 0;
+    }
     if (lds_bytes > 160 * 1024) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident kernel");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool prof = g->prof_on && (size_t)(2 * g->prof_n + 1) < g->prof_ev.size();

@@ -37,6 +37,7 @@ struct fgnn_graph {
     int tpc, cpb;  // threads per codeword, codewords per block
     bool user_launch;
     bool shortcut = true;        // exact wave-uniform shortcuts for saturated nodes (fgnn_graph_set_option)
+    bool early_exit = true;      // exact fixed-point exit of the iteration loop (needs shortcut; fgnn_graph_set_option)
     bool force_generic = false;  // testing: run the runtime-degree kernel even on a regular graph
     std::vector<void*> allocs;
     // host copies of the canonical edge lists (fgnn_graph_edges)

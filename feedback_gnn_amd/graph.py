@@ -110,6 +110,10 @@ class TannerGraph:
         """Exact wave-uniform shortcut for saturated nodes in the regular BP4 kernel (default on; same results)."""
         check(_lib.lib().fgnn_graph_set_option(self.handle, 1, int(bool(on))))
 
+    def set_fixed_point_exit(self, on=True):
+        """Exact early exit of converged codewords (FGNN_OPT_FIXED_POINT_EXIT; only acts with the saturation shortcut on)."""
+        check(_lib.lib().fgnn_graph_set_option(self.handle, 2, int(bool(on))))
+
     def force_generic(self, on=True):
         """Testing hook: run the runtime-degree kernel even on a degree-regular graph."""
         check(_lib.lib().fgnn_graph_force_generic(self.handle, int(bool(on))))

@@ -67,8 +67,12 @@ int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords
  * of a wave whose 64 nodes are all saturated (|v->c| >= 16.635532 at a check; totals beyond the softplus threshold
  * and 20 apart at a qubit), writing the values those evaluations produce bit for bit (phi(clip max) = 0,
  * phi(clip min), log(1) = 0).  Results are identical with 0 and 1; 0 evaluates every transcendental like the
- * reference's fixed dataflow (decoding_q.py:732-767) and is what bench.py's headline number uses. */
-enum { FGNN_OPT_SATURATION_SHORTCUT = 1 };
+ * reference's fixed dataflow (decoding_q.py:732-767) and is what bench.py's headline number uses.
+ * FGNN_OPT_FIXED_POINT_EXIT (default 1, effective only with the shortcut on, boxplus-phi, one codeword per workgroup):
+ * when two consecutive check-node phases were all-saturated and no c->v sign changed in between, the messages are at a
+ * bit-exact fixed point of the (deterministic) iteration map, every remaining iteration is the identity, and the
+ * workgroup leaves the loop.  Results are identical with 0 and 1. */
+enum { FGNN_OPT_SATURATION_SHORTCUT = 1, FGNN_OPT_FIXED_POINT_EXIT = 2 };
 int fgnn_graph_set_option(fgnn_graph* g, int option, int value);
 /* Testing hook: on != 0 forces the runtime-degree (CSR) kernel even on a degree-regular graph. */
 int fgnn_graph_force_generic(fgnn_graph* g, int on);

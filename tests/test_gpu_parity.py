@@ -233,6 +233,42 @@ def test_saturation_shortcut_is_exact(name, p):
         gg.set_saturation_shortcut(True)
 
 
+@pytest.mark.parametrize("name,p,iters,factor", [("ghp882", 0.01, 64, 1.0), ("ghp882", 0.05, 64, 1.0), ("ghp882", 0.09, 64, 1.0),
+                                                  ("ghp882", 0.03, 200, 1.0), ("ghp882", 0.03, 3, 1.0), ("ghp882", 0.04, 7, 0.8),
+                                                  ("ghp1270", 0.02, 64, 1.0), ("ghp1270", 0.09, 48, 0.9)])
+def test_fixed_point_exit_is_exact(name, p, iters, factor):
+    """FGNN_OPT_FIXED_POINT_EXIT: a workgroup leaves the iteration loop once its messages are provably at a bit-exact fixed
+    point.  With the exit on, off, and with the shortcut off altogether the kernel must reproduce the oracle (which runs
+    every iteration) bit for bit — messages, marginals, decisions, soft syndromes — for converged, oscillating and
+    non-converged samples alike, also when launched with few or many iterations."""
+    B = 96
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, p, B, first=4242)
+    gg = gpu_graph(name)
+    L0 = llr_const(0.05)
+    o = oracle_graph(name).bp4_decode(sx, sz, iters, "boxplus-phi", factor, llr_const=L0, return_msgs=True)
+    try:
+        for shortcut, fpe in ((True, True), (True, False), (False, True)):
+            gg.set_saturation_shortcut(shortcut)
+            gg.set_fixed_point_exit(fpe)
+            g = gg.bp4_decode(tx, tz, iters, "boxplus-phi", factor, llr_const=L0, return_msgs=True)
+            _assert_bp_equal(o, g, f"shortcut={shortcut} exit={fpe}")
+        gg.set_saturation_shortcut(True)
+        gg.set_fixed_point_exit(True)
+        # chained launches (stage-two style): restart from the returned messages, with per-qubit channel LLRs
+        llr = np.random.RandomState(5).uniform(0.5, 3.0, size=(B, 3, gg.n)).astype(np.float32)
+        o1 = oracle_graph(name).bp4_decode(sx, sz, iters, "boxplus-phi", factor, llr_ch=llr, return_msgs=True)
+        o2 = oracle_graph(name).bp4_decode(sx, sz, 5, "boxplus-phi", factor, llr_ch=llr, msg_init=(o1["msg_x"], o1["msg_z"]),
+                                           return_msgs=True)
+        g1 = gg.bp4_decode(tx, tz, iters, "boxplus-phi", factor, llr_ch=to_gpu(llr), return_msgs=True)
+        g2 = gg.bp4_decode(tx, tz, 5, "boxplus-phi", factor, llr_ch=to_gpu(llr), msg_init=(g1["msg_x"], g1["msg_z"]),
+                           return_msgs=True)
+        _assert_bp_equal(o1, g1, "llr_ch")
+        _assert_bp_equal(o2, g2, "restart")
+    finally:
+        gg.set_saturation_shortcut(True)
+        gg.set_fixed_point_exit(True)
+
+
 def _gnnbp4_weights(seed=11):
     from feedback_gnn_amd.graph import GNNBP4_SHAPES
     rng = np.random.RandomState(seed)
