@@ -159,14 +159,20 @@ __global__ void __launch_bounds__(1024) residual_kernel(GraphDev g, int RX, int 
     uint8_t* xd = sm + ((cpb * sizeof(unsigned) + 15) & ~size_t(15)) + (size_t)cwl * 2 * n;
     uint8_t* zd = xd + n;
     if (lane == 0) fl[cwl] = 0;
+    __syncthreads();
+    unsigned any_diff = 0;
     if (active)
         for (int v = lane; v < n; v += tpc) {
             xd[v] = ex[(size_t)b * n + v] ^ xh[(size_t)b * n + v];  // (:346)
             zd[v] = ez[(size_t)b * n + v] ^ zh[(size_t)b * n + v];  // (:347)
+            any_diff |= xd[v] | zd[v];
         }
+    // bit 2 of the flag word: the decision differs from the error somewhere.  When it does not (the usual case below
+    // threshold) every parity below is a parity of zeros: the row loops are skipped unless the arrays were asked for.
+    if (any_diff) atomicOr(&fl[cwl], 4u);
     __syncthreads();
     unsigned mine = 0;
-    if (active) {
+    if (active && ((fl[cwl] & 4u) || s_hat || ls_hat)) {
         const int ms = g.m_z + g.m_x;
         // s_hat = [hz xd ; hx zd]  (:349-350,:355): combined check c: hx rows first, so remap
         for (int c = lane; c < g.m; c += tpc) {
@@ -191,7 +197,7 @@ __global__ void __launch_bounds__(1024) residual_kernel(GraphDev g, int RX, int 
     }
     if (mine) atomicOr(&fl[cwl], mine);
     __syncthreads();
-    if (active && lane == 0 && flags) flags[b] = (uint8_t)fl[cwl];
+    if (active && lane == 0 && flags) flags[b] = (uint8_t)(fl[cwl] & 3u);
 }
 
 __global__ void __launch_bounds__(256) count_kernel(const uint8_t* __restrict__ flags, int B, unsigned long long* counts)
