@@ -71,6 +71,7 @@ _SIGNATURES = {
     "fgnn_gnnbp4_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "fgnn_gnnbp4_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6
                            + [C.c_size_t, C.c_void_p]),
+    "fgnn_weights_create_general": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "fgnn_bp4_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
                           + [C.c_void_p] * 7),
     "fgnn_feedback_gnn_backward": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 9),

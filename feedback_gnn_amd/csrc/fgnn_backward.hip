@@ -425,6 +425,9 @@ extern "C" int fgnn_feedback_gnn_backward(const fgnn_graph* g, const fgnn_weight
         if (!edge_feat[s] || !edge_h1[s] || !edge_d1[s] || !edge_dm[s]) return fgnn_fail(FGNN_ERR_ARG, "buffer is NULL");
     if (B < 0) return fgnn_fail(FGNN_ERR_ARG, "B must be >= 0");
     if (w->device != g->device) return fgnn_fail(FGNN_ERR_ARG, "weights and graph live on different devices");
+    if (w->general)
+        return fgnn_fail(FGNN_ERR_ARG, "the reverse pass exists for the num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, "
+                                       "mean, tanh, use_bias configuration only");
     if (B == 0) return FGNN_OK;
     FGNN_HIP_CHECK(hipSetDevice(g->device));
     GnnBwArgs a;

@@ -257,6 +257,112 @@ __global__ void __launch_bounds__(1024) gnn_kernel(GraphDev g, WeightsDev w, Gnn
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Runtime-shaped Feedback_GNN (any num_msg_dims / num_hidden_units / num_mlp_layers / reduce_op / activation / use_bias the
+// reference's constructor accepts within the limits of fgnn.h): one thread per qubit, Dense = fmaf chain in ascending k from 0
+// then (+ bias) then activation, exactly as the oracle (og_feedback_gnn_general).  Activations of one layer ping-pong between
+// two per-thread buffers (scratch memory: this is the compatibility path, not the benchmark path).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gen_act(float a, int act)
+{
+    switch (act) {
+    case FGNN_ACT_TANH: return fg_tanh(a);
+    case FGNN_ACT_RELU: return FG_MAX(a, 0.0f);
+    case FGNN_ACT_SIGMOID: return fg_sigmoid(a);
+    default: return a;
+    }
+}
+
+__device__ __forceinline__ void gen_dense(const GnnGeneralDev& w, int li, const float* in, float* out)
+{
+    const int K = w.K[li], J = w.J[li], act = w.act_l[li];
+    const float* W = w.W[li];
+    const float* b = w.b[li];
+    for (int j = 0; j < J; ++j) {
+        float a = 0.0f;
+        for (int k = 0; k < K; ++k) a = FG_FMA(in[k], W[k * J + j], a);
+        if (b) a = a + b[j];
+        out[j] = gen_act(a, act);
+    }
+}
+
+__global__ void __launch_bounds__(1024) gnn_general_kernel(GraphDev g, GnnGeneralDev w, GnnArgs a)
+{
+    extern __shared__ float lds[];
+    const int cwl = threadIdx.x / a.tpc;
+    const int lane = threadIdx.x - cwl * a.tpc;
+    const int slot_b = blockIdx.x * a.cpb + cwl;
+    const bool active = slot_b < a.B;
+    const int b = (active && a.index) ? a.index[slot_b] : slot_b;
+    float* gcn = lds + (size_t)cwl * a.lds_per_cw;
+    const int n = g.n;
+    if (active) {
+        for (int c = lane; c < g.m_x; c += a.tpc)
+            gcn[c] = a.logit_hx[(size_t)b * g.m_x + c] * ((a.synd_x[(size_t)b * g.m_x + c] & 1) ? -1.0f : 1.0f);
+        for (int c = lane; c < g.m_z; c += a.tpc)
+            gcn[g.m_x + c] = a.logit_hz[(size_t)b * g.m_z + c] * ((a.synd_z[(size_t)b * g.m_z + c] & 1) ? -1.0f : 1.0f);
+    }
+    __syncthreads();
+    if (!active) return;
+    const float* in = a.llr + (size_t)b * 3 * n;
+    float* out = a.out + (size_t)b * 3 * n;
+    const int D = w.D, L = w.L;
+    for (int v = lane; v < n; v += a.tpc) {
+        const float X = in[v], Y = in[n + v], Z = in[2 * n + v];
+        float bufA[FGNN_GEN_MAX_W], bufB[FGNN_GEN_MAX_W], z[2 * FGNN_GEN_MAX_D + 3];
+        for (int s = 0; s < 2; ++s) {
+            const int* vptr = s == 0 ? g.vptr_x : g.vptr_z;
+            const float* gc = s == 0 ? gcn : gcn + g.m_x;
+            const int e0 = vptr[v], e1 = vptr[v + 1];
+            float* acc = z + s * D;
+            for (int i = 0; i < D; ++i) acc[i] = 0.0f;
+            for (int e = e0; e < e1; ++e) {
+                float* cur = bufA;
+                float* nxt = bufB;
+                cur[0] = gc[g.vchk[e]];  // (:175-178)
+                cur[1] = X;
+                cur[2] = Y;
+                cur[3] = Z;
+                for (int l = 0; l < L; ++l) {
+                    gen_dense(w, s * L + l, cur, nxt);
+                    float* t = cur;
+                    cur = nxt;
+                    nxt = t;
+                }
+                for (int i = 0; i < D; ++i) {  // reduce_msg (:130-150), edges in ascending check order
+                    const float m = cur[i];
+                    float r;
+                    if (e == e0) r = m;
+                    else if (w.reduce_op == FGNN_REDUCE_MAX) r = FG_MAX(acc[i], m);
+                    else if (w.reduce_op == FGNN_REDUCE_MIN) r = FG_MIN(acc[i], m);
+                    else r = acc[i] + m;
+                    acc[i] = r;
+                }
+            }
+            if (w.reduce_op == FGNN_REDUCE_MEAN && e1 > e0) {
+                const float fd = (float)(e1 - e0);
+                for (int i = 0; i < D; ++i) acc[i] = acc[i] / fd;
+            }
+        }
+        z[2 * D] = X;
+        z[2 * D + 1] = Y;
+        z[2 * D + 2] = Z;
+        const float* cur = z;
+        float* nxt = bufA;
+        for (int l = 0; l < L - 1; ++l) {  // vn_embed_mlp (:186)
+            gen_dense(w, 2 * L + l, cur, nxt);
+            cur = nxt;
+            nxt = (nxt == bufA) ? bufB : bufA;
+        }
+        float o[3];
+        gen_dense(w, 3 * L - 1, cur, o);  // _llr_inv_embed
+        out[v] = o[0];
+        out[n + v] = o[1];
+        out[2 * n + v] = o[2];
+    }
+}
+
 }  // namespace
 
 extern "C" int fgnn_weights_create(const float* const host_arrays[12], int device, fgnn_weights** out)
@@ -362,6 +468,77 @@ extern "C" int fgnn_weights_create(const float* const host_arrays[12], int devic
     return FGNN_OK;
 }
 
+extern "C" int fgnn_weights_create_general(const fgnn_gnn_config* cfg, const float* const* host_arrays, int num_arrays,
+                                           int device, fgnn_weights** out)
+{
+    if (!cfg || !host_arrays || !out) return fgnn_fail(FGNN_ERR_ARG, "NULL argument");
+    const int D = cfg->num_msg_dims, H = cfg->num_hidden_units, L = cfg->num_mlp_layers, bias = cfg->use_bias ? 1 : 0;
+    if (D < 1 || D > FGNN_GEN_MAX_D || L < 1 || L > 4 || (L > 1 && (H < 1 || H > FGNN_GEN_MAX_W)))
+        return fgnn_fail(FGNN_ERR_ARG, "general feedback GNN: need 1 <= num_msg_dims <= 32, 1 <= num_hidden_units <= 96, "
+                                       "1 <= num_mlp_layers <= 4");
+    if (cfg->reduce_op < 0 || cfg->reduce_op > 3) return fgnn_fail(FGNN_ERR_ARG, "unknown reduce operation");  // :148
+    if (cfg->activation < 0 || cfg->activation > 3) return fgnn_fail(FGNN_ERR_ARG, "unsupported activation");
+    if (num_arrays != 3 * L * (1 + bias)) return fgnn_fail(FGNN_ERR_ARG, "wrong number of weight arrays for this configuration");
+    for (int i = 0; i < num_arrays; ++i)
+        if (!host_arrays[i]) return fgnn_fail(FGNN_ERR_ARG, "weight array is NULL");
+    FGNN_HIP_CHECK(hipSetDevice(device));
+    fgnn_weights* w = new fgnn_weights();
+    w->device = device;
+    w->blob = nullptr;
+    w->general = true;
+    std::memset(&w->d, 0, sizeof(w->d));
+    GnnGeneralDev& G = w->gen;
+    std::memset(&G, 0, sizeof(G));
+    G.D = D; G.H = H; G.L = L; G.reduce_op = cfg->reduce_op; G.act = cfg->activation; G.bias = bias; G.nl = 3 * L;
+    // execution order -> (K, J, activation); file order: _llr_inv_embed first, then msg_x, msg_z, embed
+    const int emb_out = L > 1 ? H : 2 * D + 3;
+    for (int s = 0; s < 2; ++s)
+        for (int l = 0; l < L; ++l) {
+            const int li = s * L + l;
+            G.K[li] = l == 0 ? 4 : H;
+            G.J[li] = l == L - 1 ? D : H;
+            G.act_l[li] = l == L - 1 ? FGNN_ACT_LINEAR : cfg->activation;
+        }
+    for (int l = 0; l < L - 1; ++l) {
+        const int li = 2 * L + l;
+        G.K[li] = l == 0 ? 2 * D + 3 : H;
+        G.J[li] = H;
+        G.act_l[li] = cfg->activation;
+    }
+    G.K[3 * L - 1] = emb_out;
+    G.J[3 * L - 1] = 3;
+    G.act_l[3 * L - 1] = FGNN_ACT_LINEAR;
+    std::vector<float> h;
+    std::vector<size_t> offW(G.nl), offB(G.nl);
+    auto file_index = [&](int li) { return li == 3 * L - 1 ? 0 : li + 1; };  // position among the Dense layers of the file
+    for (int li = 0; li < G.nl; ++li) {
+        const int f = file_index(li) * (1 + bias);
+        const size_t cnt = (size_t)G.K[li] * G.J[li];
+        offW[li] = h.size();
+        h.insert(h.end(), host_arrays[f], host_arrays[f] + cnt);
+        h.resize((h.size() + 3) & ~size_t(3), 0.0f);
+        offB[li] = h.size();
+        if (bias) {
+            h.insert(h.end(), host_arrays[f + 1], host_arrays[f + 1] + G.J[li]);
+            h.resize((h.size() + 3) & ~size_t(3), 0.0f);
+        }
+    }
+    hipError_t e = hipMalloc(&w->blob, h.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(w->blob, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (w->blob) (void)hipFree(w->blob);
+        delete w;
+        return fgnn_fail(FGNN_ERR_HIP, std::string("weights upload: ") + hipGetErrorString(e));
+    }
+    const float* base = static_cast<const float*>(w->blob);
+    for (int li = 0; li < G.nl; ++li) {
+        G.W[li] = base + offW[li];
+        G.b[li] = bias ? base + offB[li] : nullptr;
+    }
+    *out = w;
+    return FGNN_OK;
+}
+
 extern "C" void fgnn_weights_destroy(fgnn_weights* w)
 {
     if (!w) return;
@@ -393,6 +570,13 @@ int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const flo
     a.synd_z = synd_z;
     a.out = out;
     a.index = index;
+    if (w->general) {
+        size_t lds_gen = (size_t)a.lds_per_cw * sizeof(float) * (size_t)L.cpb;
+        hipLaunchKernelGGL(gnn_general_kernel, dim3(L.blocks), dim3(L.threads), lds_gen, static_cast<hipStream_t>(stream), g->d,
+                           w->gen, a);
+        FGNN_HIP_CHECK(hipGetLastError());
+        return FGNN_OK;
+    }
     if (g->d.dvx == 3 && g->d.dvz == 3 && !g->force_generic) {
         // degree-regular graph: MFMA kernel, one codeword per 256-thread workgroup
         hipLaunchKernelGGL(gnn_mfma_kernel<3>, dim3(B), dim3(256), (size_t)(T_COUNT * 64 + a.lds_per_cw) * sizeof(float),

@@ -65,10 +65,23 @@ struct WeightsDev {
     const float* lane_tab;  // [132][64] per-lane MFMA operand / bias tables (fgnn_gnn.hip, mfma path)
 };
 
+// Runtime-shaped feedback GNN (fgnn_weights_create_general): Dense layers in execution order
+//   [0, L) vn_msg_mlp_x | [L, 2L) vn_msg_mlp_z | [2L, 3L-1) vn_embed_mlp | 3L-1 _llr_inv_embed
+constexpr int FGNN_GEN_MAX_LAYERS = 12;
+constexpr int FGNN_GEN_MAX_D = 32, FGNN_GEN_MAX_W = 96;
+struct GnnGeneralDev {
+    int D, H, L, reduce_op, act, bias, nl;
+    int K[FGNN_GEN_MAX_LAYERS], J[FGNN_GEN_MAX_LAYERS], act_l[FGNN_GEN_MAX_LAYERS];
+    const float* W[FGNN_GEN_MAX_LAYERS];  // [K][J]
+    const float* b[FGNN_GEN_MAX_LAYERS];  // [J] or null
+};
+
 struct fgnn_weights {
     WeightsDev d;
     int device;
     void* blob;
+    bool general = false;
+    GnnGeneralDev gen;
 };
 
 void fgnn_set_error(const std::string& s);

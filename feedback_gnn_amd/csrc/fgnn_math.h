@@ -194,4 +194,12 @@ FG_FN float fg_atanh(float x)
     return fg_u2f(fg_f2u(r) | (fg_f2u(x) & 0x80000000u));
 }
 
+/* logistic sigmoid 1/(1+e^-x) (Keras 'sigmoid' activation of the general feedback GNN), stable on both sides */
+FG_FN float fg_sigmoid(float x)
+{
+    float e = fg_exp(-FG_MIN(FG_ABS(x), 87.0f));
+    float d = 1.0f + e;
+    return (x >= 0.0f) ? 1.0f / d : e / d;
+}
+
 #endif /* FGNN_MATH_H */

@@ -8,7 +8,7 @@ libfgnn_hip.so (include/fgnn.h); tensors are torch tensors on the HIP device.
 import numpy as np
 import torch
 
-from .graph import GnnWeights, TannerGraph
+from .graph import ACTIVATIONS, REDUCE_OPS, SHIPPED_GNN_CONFIG, GnnWeights, TannerGraph, gnn_weight_shapes
 from .weights_io import read_weight_list
 
 _W_SHAPES = [(40, 3), (3,), (4, 40), (40,), (40, 20), (20,), (4, 40), (40,), (40, 20), (20,), (43, 40), (40,)]
@@ -22,9 +22,11 @@ def _glorot_uniform(rng, shape):
 class Feedback_GNN:
     """One CN->VN message-passing layer that maps BP marginals + soft syndromes to new channel LLRs.
 
-    Constructor as feedback_gnn.py:21-28.  The HIP kernel implements the architecture the reference
-    trains and ships (n882.py:45-51): num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2,
-    reduce_op="mean", activation="tanh", use_bias=True; other settings raise NotImplementedError.
+    Constructor as feedback_gnn.py:21-28.  The architecture the reference trains and ships (n882.py:45-51:
+    num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean", activation="tanh", use_bias=True) runs on the
+    MFMA kernel and has a reverse pass; any other setting with num_msg_dims <= 32, num_hidden_units <= 96,
+    num_mlp_layers <= 4, reduce_op in sum/mean/max/min, activation in tanh/relu/sigmoid/linear runs on the runtime-shaped
+    kernel (forward only).  ``get_weights()`` / ``set_weights()`` / ``load_weights`` use Keras' array order for the setting.
 
     Call: ``G((h_vn[bs,n,3], logit_hx[m_x,bs], logit_hz[m_z,bs], syndrome_x[m_x,bs], syndrome_z[m_z,bs]))``
     → ``[bs,n,3]`` (new llrx, llry, llrz).
@@ -33,10 +35,14 @@ class Feedback_GNN:
     def __init__(self, code, num_msg_dims, num_hidden_units, num_mlp_layers, reduce_op="mean", activation="tanh",
                  use_bias=False, device=None, graph=None, seed=0):
         cfg = (int(num_msg_dims), int(num_hidden_units), int(num_mlp_layers), reduce_op, activation, bool(use_bias))
-        if cfg != (20, 40, 2, "mean", "tanh", True):
-            raise NotImplementedError(
-                "the gfx950 kernel is specialised for num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, "
-                f"reduce_op='mean', activation='tanh', use_bias=True (the shipped weights); got {cfg}")
+        if reduce_op not in REDUCE_OPS:
+            raise ValueError("unknown reduce operation")  # feedback_gnn.py:148
+        if activation not in ACTIVATIONS:
+            raise NotImplementedError(f"activation {activation!r}: the HIP kernels implement tanh, relu, sigmoid and linear")
+        if not (1 <= cfg[0] <= 32 and 1 <= cfg[2] <= 4 and (cfg[2] == 1 or 1 <= cfg[1] <= 96)):
+            raise NotImplementedError("the runtime-shaped kernel takes num_msg_dims <= 32, num_hidden_units <= 96, "
+                                      f"1 <= num_mlp_layers <= 4; got {cfg[:3]}")
+        self._config = cfg
         self._num_msg_dims, self._num_hidden_units, self._num_mlp_layers = cfg[:3]
         self._reduce_op, self._activation, self._use_bias = cfg[3:]
         self.graph = graph if graph is not None else TannerGraph(code, stage_one=True, device=device)
@@ -46,19 +52,25 @@ class Feedback_GNN:
         # Keras initialisers of feedback_gnn.py:115-128 / gnn.py:55-61: Dense kernels glorot-uniform,
         # biases ones, the output layer's kernel zeros.
         rng = np.random.RandomState(seed)
+        self._shapes = gnn_weight_shapes(*cfg[:3], use_bias=cfg[5])
         w = []
-        for shp in _W_SHAPES:
+        for shp in self._shapes:
             w.append(np.ones(shp, np.float32) if len(shp) == 1 else _glorot_uniform(rng, shp))
-        w[0] = np.zeros(_W_SHAPES[0], np.float32)
+        w[0] = np.zeros(self._shapes[0], np.float32)
         self._weights = self._vars = self._var_versions = None
         self.set_weights(w)
+
+    @property
+    def is_shipped_architecture(self):
+        """True for num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, mean, tanh, bias: the MFMA kernel and the reverse pass."""
+        return self._config == SHIPPED_GNN_CONFIG
 
     def get_weights(self):
         self._sync()
         return [a.copy() for a in self._weights.arrays]
 
     def set_weights(self, weights):
-        self._weights = GnnWeights(list(weights), self.graph.device)
+        self._weights = GnnWeights(list(weights), self.graph.device, self._config)
         self._vars = self._var_versions = None
 
     @property
@@ -74,7 +86,7 @@ class Feedback_GNN:
 
     def _sync(self):
         if self._vars is not None and [v._version for v in self._vars] != self._var_versions:
-            self._weights = GnnWeights([v.detach().cpu().numpy() for v in self._vars], self.graph.device)
+            self._weights = GnnWeights([v.detach().cpu().numpy() for v in self._vars], self.graph.device, self._config)
             self._var_versions = [v._version for v in self._vars]
 
     @property
@@ -83,7 +95,7 @@ class Feedback_GNN:
         return self._weights
 
     def count_params(self):
-        return int(sum(int(np.prod(s)) for s in _W_SHAPES))
+        return int(sum(int(np.prod(s)) for s in self._shapes))
 
     def __call__(self, inputs):
         h_vn, logit_hx, logit_hz, syndrome_x, syndrome_z = inputs
@@ -293,6 +305,9 @@ class Second_Stage_GNN_BP_Model:
     def value_and_grad(self, noise_x, noise_z, h_vn, logit_hx_perp, logit_hz_perp):
         """``(s_hat, ls_hat, loss, grads)``: what ``with tf.GradientTape() as tape: ... = model(...)`` followed by
         ``tape.gradient(loss, model.trainable_variables)`` yields in Feedback_GNN.ipynb cell 8."""
+        if not self.feedback.is_shipped_architecture:
+            raise NotImplementedError("the reverse pass exists for num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, "
+                                      "reduce_op='mean', activation='tanh', use_bias=True only")
         g, ex, ez, sx, sz = self._inputs(noise_x, noise_z, h_vn, logit_hx_perp, logit_hz_perp)
         dev = g.device
         llr_in = torch.as_tensor(h_vn, device=dev, dtype=torch.float32).permute(0, 2, 1).contiguous()

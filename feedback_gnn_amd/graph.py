@@ -31,19 +31,52 @@ def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-class GnnWeights:
-    """Device copy of one feedback GNN's 12 weight arrays (fgnn_weights)."""
+REDUCE_OPS = {"sum": 0, "mean": 1, "max": 2, "min": 3}
+ACTIVATIONS = {None: 0, "linear": 0, "tanh": 1, "relu": 2, "sigmoid": 3}
+SHIPPED_GNN_CONFIG = (20, 40, 2, "mean", "tanh", True)
 
-    def __init__(self, arrays, device):
+
+def gnn_weight_shapes(num_msg_dims, num_hidden_units, num_mlp_layers, use_bias=True):
+    """Shapes of Feedback_GNN.get_weights() (feedback_gnn.py:110-128): _llr_inv_embed, vn_msg_mlp_x, vn_msg_mlp_z, vn_embed_mlp."""
+    D, H, L = int(num_msg_dims), int(num_hidden_units), int(num_mlp_layers)
+    dense = [(H if L > 1 else 2 * D + 3, 3)]
+    for _ in range(2):
+        dense += [(4 if l == 0 else H, D if l == L - 1 else H) for l in range(L)]
+    dense += [(2 * D + 3 if l == 0 else H, H) for l in range(L - 1)]
+    shapes = []
+    for k, j in dense:
+        shapes.append((k, j))
+        if use_bias:
+            shapes.append((j,))
+    return shapes
+
+
+class GnnWeights:
+    """Device copy of one feedback GNN's weight arrays (fgnn_weights).  ``config`` = (num_msg_dims, num_hidden_units,
+    num_mlp_layers, reduce_op, activation, use_bias); the shipped configuration takes the MFMA kernel, any other one the
+    runtime-shaped kernel (fgnn_weights_create_general)."""
+
+    def __init__(self, arrays, device, config=SHIPPED_GNN_CONFIG, force_general=False):
         arrays = [np.ascontiguousarray(a, dtype=np.float32) for a in arrays]
-        shapes = [(40, 3), (3,), (4, 40), (40,), (40, 20), (20,), (4, 40), (40,), (40, 20), (20,), (43, 40), (40,)]
+        D, H, L, red, act, bias = config
+        if red not in REDUCE_OPS:
+            raise ValueError("unknown reduce operation")  # feedback_gnn.py:148
+        if act not in ACTIVATIONS:
+            raise NotImplementedError(f"activation {act!r}: the HIP kernels implement {sorted(k for k in ACTIVATIONS if k)}")
+        shapes = gnn_weight_shapes(D, H, L, bias)
         if [a.shape for a in arrays] != shapes:
             raise ValueError(f"feedback-GNN weights must have shapes {shapes}, got {[a.shape for a in arrays]}")
         self.arrays = arrays
+        self.config = (int(D), int(H), int(L), red, act, bool(bias))
         self.device = torch.device(device)
-        ptrs = (C.c_void_p * 12)(*[a.ctypes.data for a in arrays])
+        self.general = force_general or self.config != SHIPPED_GNN_CONFIG
+        ptrs = (C.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
         h = C.c_void_p()
-        check(_lib.lib().fgnn_weights_create(ptrs, self.device.index or 0, C.byref(h)))
+        if self.general:
+            cfg = (C.c_int * 6)(int(D), int(H), int(L), REDUCE_OPS[red], ACTIVATIONS[act], int(bool(bias)))
+            check(_lib.lib().fgnn_weights_create_general(cfg, ptrs, len(arrays), self.device.index or 0, C.byref(h)))
+        else:
+            check(_lib.lib().fgnn_weights_create(ptrs, self.device.index or 0, C.byref(h)))
         self.handle = h
 
     def __del__(self):

@@ -106,6 +106,24 @@ int fgnn_bp4_decode(const fgnn_graph* g, int cn_type, int num_iter, float normal
 int fgnn_weights_create(const float* const host_arrays[12], int device, fgnn_weights** out);
 void fgnn_weights_destroy(fgnn_weights* w);
 
+/* Feedback_GNN with other hyper-parameters than the shipped weights' (constructor feedback_gnn.py:21-28, build :110-128):
+ * num_msg_dims D <= 32, num_hidden_units H <= 96, num_mlp_layers L in 1..4, reduce_op (:139-148), the activation of the
+ * hidden layers, use_bias.  host_arrays = Layer.get_weights() order: _llr_inv_embed [(L>1 ? H : 2D+3), 3] (+ bias),
+ * vn_msg_mlp_x: L Dense layers 4 -> H -> ... -> D, vn_msg_mlp_z: likewise, vn_embed_mlp: L-1 Dense layers 2D+3 -> H -> ... -> H;
+ * every kernel [in, out] row-major, a bias array after each kernel iff use_bias.  num_arrays must equal
+ * (3L) * (1 + use_bias).  The handle is accepted wherever fgnn_weights is (fgnn_feedback_gnn, fgnn_sandwich_decode); it runs
+ * a runtime-shaped VALU kernel (the MFMA kernel is specialised for D=20, H=40, L=2, mean, tanh, bias). */
+typedef struct {
+    int num_msg_dims, num_hidden_units, num_mlp_layers;
+    int reduce_op;   /* FGNN_REDUCE_* */
+    int activation;  /* FGNN_ACT_* */
+    int use_bias;
+} fgnn_gnn_config;
+enum { FGNN_REDUCE_SUM = 0, FGNN_REDUCE_MEAN = 1, FGNN_REDUCE_MAX = 2, FGNN_REDUCE_MIN = 3 };
+enum { FGNN_ACT_LINEAR = 0, FGNN_ACT_TANH = 1, FGNN_ACT_RELU = 2, FGNN_ACT_SIGMOID = 3 };
+int fgnn_weights_create_general(const fgnn_gnn_config* cfg, const float* const* host_arrays, int num_arrays, int device,
+                                fgnn_weights** out);
+
 /* Feedback_GNN.call, feedback_gnn.py:161-188 (reduce_op="mean", activation="tanh", 2-layer MLPs):
  *   llr [B,3,n] = h_vn planes (llrx, llry, llrz);  logit_hx [B,m_x], logit_hz [B,m_z] soft syndromes
  *   of the hx / hz rows;  out [B,3,n] = new channel LLRs for the next BP run. */

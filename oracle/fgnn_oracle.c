@@ -475,6 +475,103 @@ int og_feedback_gnn(const og_graph* g, const float* const* w, const float* llr, 
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Feedback_GNN.call for any constructor setting (feedback_gnn.py:21-28, build :110-128, call :161-188, reduce_msg :130-150):
+ * D = num_msg_dims, H = num_hidden_units, L = num_mlp_layers, reduce_op 0 sum / 1 mean / 2 max / 3 min, activation 0 linear /
+ * 1 tanh / 2 relu / 3 sigmoid, use_bias.  w = Layer.get_weights() order: _llr_inv_embed, vn_msg_mlp_x (L Dense), vn_msg_mlp_z
+ * (L Dense), vn_embed_mlp (L-1 Dense); kernels [in,out]; a bias after each kernel iff use_bias.
+ * ------------------------------------------------------------------------------------------ */
+static float gen_act(float a, int act)
+{
+    switch (act) {
+    case 1: return fg_tanh(a);
+    case 2: return FG_MAX(a, 0.0f);
+    case 3: return fg_sigmoid(a);
+    default: return a;
+    }
+}
+
+/* one Dense layer, gnn.py:63-69: matmul (fmaf chain in ascending k from 0), bias add, activation */
+static void gen_dense(const float* W, const float* b, int K, int J, int act, const float* in, float* out)
+{
+    for (int j = 0; j < J; ++j) {
+        float a = 0.0f;
+        for (int k = 0; k < K; ++k) a = FG_FMA(in[k], W[k * J + j], a);
+        if (b) a = a + b[j];
+        out[j] = gen_act(a, act);
+    }
+}
+
+int og_feedback_gnn_general(const og_graph* g, int D, int H, int L, int reduce_op, int act, int use_bias,
+                            const float* const* w, const float* llr, const float* logit_hx, const float* logit_hz,
+                            const uint8_t* synd_x, const uint8_t* synd_z, int B, float* out)
+{
+    if (D < 1 || D > 32 || L < 1 || L > 4 || (L > 1 && (H < 1 || H > 96)) || reduce_op < 0 || reduce_op > 3 || act < 0 || act > 3)
+        return -1;
+    const int n = g->n, st = use_bias ? 2 : 1;
+    /* file position of the k-th Dense of each MLP */
+#define W_OF(idx) (w[(idx) * st])
+#define B_OF(idx) (use_bias ? w[(idx) * st + 1] : NULL)
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int b = 0; b < B; ++b) {
+        const float* l = llr + (size_t)b * 3 * n;
+        float* o = out + (size_t)b * 3 * n;
+        float bufA[96], bufB[96], z[67];
+        for (int v = 0; v < n; ++v) {
+            const float X = l[v], Y = l[n + v], Z = l[2 * n + v];
+            for (int s = 0; s < 2; ++s) {
+                const float* logit = s == 0 ? logit_hx + (size_t)b * g->m[0] : logit_hz + (size_t)b * g->m[1];
+                const uint8_t* synd = s == 0 ? synd_x + (size_t)b * g->m[0] : synd_z + (size_t)b * g->m[1];
+                float* acc = z + s * D;
+                for (int i = 0; i < D; ++i) acc[i] = 0.0f;
+                const int e0 = g->vptr[s][v], e1 = g->vptr[s][v + 1];
+                for (int e = e0; e < e1; ++e) {
+                    const int c = g->vchk[s][e];
+                    float* cur = bufA;
+                    float* nxt = bufB;
+                    cur[0] = logit[c] * (synd[c] ? -1.0f : 1.0f); /* (:168-172) */
+                    cur[1] = X;
+                    cur[2] = Y;
+                    cur[3] = Z;
+                    for (int k = 0; k < L; ++k) {
+                        const int idx = 1 + s * L + k; /* after _llr_inv_embed */
+                        gen_dense(W_OF(idx), B_OF(idx), k == 0 ? 4 : H, k == L - 1 ? D : H, k == L - 1 ? 0 : act, cur, nxt);
+                        float* t = cur; cur = nxt; nxt = t;
+                    }
+                    for (int i = 0; i < D; ++i) {
+                        const float m = cur[i];
+                        if (e == e0) acc[i] = m;
+                        else if (reduce_op == 2) acc[i] = FG_MAX(acc[i], m);
+                        else if (reduce_op == 3) acc[i] = FG_MIN(acc[i], m);
+                        else acc[i] = acc[i] + m;
+                    }
+                }
+                if (reduce_op == 1 && e1 > e0)
+                    for (int i = 0; i < D; ++i) acc[i] = acc[i] / (float)(e1 - e0);
+            }
+            z[2 * D] = X;
+            z[2 * D + 1] = Y;
+            z[2 * D + 2] = Z;
+            const float* cur = z;
+            float* nxt = bufA;
+            for (int k = 0; k < L - 1; ++k) {
+                const int idx = 1 + 2 * L + k;
+                gen_dense(W_OF(idx), B_OF(idx), k == 0 ? 2 * D + 3 : H, H, act, cur, nxt);
+                cur = nxt;
+                nxt = (nxt == bufA) ? bufB : bufA;
+            }
+            float r[3];
+            gen_dense(W_OF(0), B_OF(0), L > 1 ? H : 2 * D + 3, 3, 0, cur, r);
+            o[v] = r[0];
+            o[n + v] = r[1];
+            o[2 * n + v] = r[2];
+        }
+    }
+#undef W_OF
+#undef B_OF
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Pauli.call, pauli.py:98-108 with px=pz=2p/3, py=p/3 (feedback_gnn.py:298).
  * tf.random.uniform is unseeded in the reference; the build defines the stream:
  * Philox4x32-10, key = seed, counter = (sample index, word block) — see fgnn_rng.h.

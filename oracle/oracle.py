@@ -39,6 +39,7 @@ def lib():
         _lib.og_bp4_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_float, C.c_void_p,
                                        C.c_void_p, C.c_int] + [C.c_void_p] * 9
         _lib.og_feedback_gnn.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_void_p]
+        _lib.og_feedback_gnn_general.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
         _lib.og_pauli_noise.argtypes = [C.c_uint64, C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib.og_syndrome.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib.og_residual.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3
@@ -159,6 +160,22 @@ class OracleGraph:
         assert llr.shape == (B, 3, self.n) and logit_hx.shape == (B, self.m_x) and logit_hz.shape == (B, self.m_z)
         out = np.empty((B, 3, self.n), np.float32)
         rc = lib().og_feedback_gnn(self.h, wp, _p(llr), _p(logit_hx), _p(logit_hz), _p(synd_x), _p(synd_z), B, _p(out))
+        assert rc == 0
+        return out
+
+    def feedback_gnn_general(self, cfg, weights, llr, logit_hx, logit_hz, synd_x, synd_z):
+        """cfg = (num_msg_dims, num_hidden_units, num_mlp_layers, reduce_op 0..3, activation 0..3, use_bias)."""
+        w = [np.ascontiguousarray(a, dtype=np.float32) for a in weights]
+        wp = (C.c_void_p * len(w))(*[a.ctypes.data for a in w])
+        llr = np.ascontiguousarray(llr, dtype=np.float32)
+        B = llr.shape[0]
+        logit_hx = np.ascontiguousarray(logit_hx, dtype=np.float32)
+        logit_hz = np.ascontiguousarray(logit_hz, dtype=np.float32)
+        synd_x = np.ascontiguousarray(synd_x, dtype=np.uint8)
+        synd_z = np.ascontiguousarray(synd_z, dtype=np.uint8)
+        out = np.empty((B, 3, self.n), np.float32)
+        rc = lib().og_feedback_gnn_general(self.h, *[int(c) for c in cfg], wp, _p(llr), _p(logit_hx), _p(logit_hz), _p(synd_x),
+                                           _p(synd_z), B, _p(out))
         assert rc == 0
         return out
 

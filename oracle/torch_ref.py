@@ -106,6 +106,47 @@ def feedback_gnn(g, w, llr, logit_hx, logit_hz, synd_x, synd_z):
     return out.permute(0, 2, 1)
 
 
+def feedback_gnn_general(g, cfg, w, llr, logit_hx, logit_hz, synd_x, synd_z):
+    """Any constructor setting of Feedback_GNN (feedback_gnn.py:110-150): cfg = (D, H, L, reduce_op, activation, use_bias) with
+    reduce_op 0 sum / 1 mean / 2 max / 3 min and activation 0 linear / 1 tanh / 2 relu / 3 sigmoid; w in get_weights() order."""
+    D, H, L, red, act, bias = cfg
+    f = {0: lambda t: t, 1: torch.tanh, 2: torch.relu, 3: torch.sigmoid}[act]
+    st = 2 if bias else 1
+
+    def dense(x, idx, a):
+        y = x @ w[idx * st]
+        if bias:
+            y = y + w[idx * st + 1]
+        return a(y)
+
+    h_vn = llr.permute(0, 2, 1)
+    ms = []
+    for s, (logit, synd) in enumerate(((logit_hx, synd_x), (logit_hz, synd_z))):
+        side = g.sides[s]
+        h_cn = (logit * (1.0 - 2.0 * synd.to(DT)))[:, :, None]
+        x = torch.cat([h_cn[:, side["chk"], :], h_vn[:, side["var"], :]], -1)
+        for k in range(L):
+            x = dense(x, 1 + s * L + k, (lambda t: t) if k == L - 1 else f)
+        cols = []
+        for v in range(g.n):  # small test graphs only
+            sel = x[:, side["var"] == v, :]
+            if sel.shape[1] == 0:
+                cols.append(torch.zeros((x.shape[0], D), dtype=DT))
+            elif red == 0:
+                cols.append(sel.sum(1))
+            elif red == 1:
+                cols.append(sel.mean(1))
+            elif red == 2:
+                cols.append(sel.max(1).values)
+            else:
+                cols.append(sel.min(1).values)
+        ms.append(torch.stack(cols, 1))
+    z = torch.cat([ms[0], ms[1], h_vn], -1)
+    for k in range(L - 1):
+        z = dense(z, 1 + 2 * L + k, f)
+    return dense(z, 0, lambda t: t).permute(0, 2, 1)
+
+
 def second_stage_loss(g, w, llr_in, logit_hx, logit_hz, synd_x, synd_z, num_iter=16, loss_from=8, factor=1.0):
     """The scalar training loss of feedback_gnn.py:434-442 and the new channel LLRs it was computed from."""
     new_llr = feedback_gnn(g, w, llr_in, logit_hx, logit_hz, synd_x, synd_z)

@@ -569,3 +569,81 @@ def test_published_rows_plain_bp4(name, iters, factor, p0, p, flagged, block, to
         r = pub / total
         sigma = np.sqrt(r * (1 - r) * (1 / total + 1 / n))
         assert abs(got / n - r) < 4 * sigma + 2 / total, (name, p, got / n, r)
+
+
+GEN_CONFIGS = [(20, 40, 2, "mean", "tanh", True), (8, 16, 1, "max", "relu", False), (12, 24, 3, "sum", "sigmoid", True),
+               (5, 7, 2, "min", None, True), (32, 96, 4, "mean", "relu", False)]
+
+
+def _gen_weights(cfg, seed=3):
+    from feedback_gnn_amd.graph import gnn_weight_shapes
+    rng = np.random.RandomState(seed)
+    return [rng.uniform(-0.5, 0.5, size=s).astype(np.float32) for s in gnn_weight_shapes(cfg[0], cfg[1], cfg[2], cfg[5])]
+
+
+def _cfg_codes(cfg):
+    from feedback_gnn_amd.graph import ACTIVATIONS, REDUCE_OPS
+    return (cfg[0], cfg[1], cfg[2], REDUCE_OPS[cfg[3]], ACTIVATIONS[cfg[4]], int(cfg[5]))
+
+
+@pytest.mark.parametrize("cfg", GEN_CONFIGS)
+@pytest.mark.parametrize("name", ["rsurf5", "ghp882"])
+def test_general_feedback_gnn_bit_exact(name, cfg):
+    """Feedback_GNN with any constructor setting (fgnn_weights_create_general, runtime-shaped kernel) against the oracle."""
+    from feedback_gnn_amd.graph import GnnWeights
+    B = 21
+    og, gg = oracle_graph(name), gpu_graph(name)
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, 0.08, B)
+    o = og.bp4_decode(sx, sz, 6, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
+    w = _gen_weights(cfg)
+    ref = og.feedback_gnn_general(_cfg_codes(cfg), w, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
+    gw = GnnWeights(w, gg.device, cfg, force_general=True)
+    got = gg.feedback_gnn(gw, to_gpu(o["llr"]), to_gpu(o["z_logit"]), to_gpu(o["x_logit"]), tx, tz).cpu().numpy()
+    assert np.array_equal(ref, got), np.abs(ref - got).max()
+    if cfg == GEN_CONFIGS[0]:  # the shipped setting: runtime-shaped, VALU and MFMA kernels all agree
+        sp = gg.feedback_gnn(GnnWeights(w, gg.device), to_gpu(o["llr"]), to_gpu(o["z_logit"]), to_gpu(o["x_logit"]), tx, tz)
+        assert np.array_equal(got, sp.cpu().numpy())
+
+
+def test_general_feedback_gnn_in_the_sandwich_and_class_surface():
+    """A non-shipped Feedback_GNN inside Sandwich_BP_GNN_Evaluation_Model equals the composition of the oracle's stages with the
+    per-sample masking of feedback_gnn.py:324-340; weights round-trip through get_weights / set_weights / save / load."""
+    import os
+    import tempfile
+    from feedback_gnn_amd import QLDPCBPDecoder, Feedback_GNN, Sandwich_BP_GNN_Evaluation_Model, load_weights, save_weights
+    name, B, p = "ghp882", 64, 0.11
+    cfg = (8, 16, 3, "max", "relu", True)
+    c = code(name)
+    og, gg = oracle_graph(name), gpu_graph(name)
+    G = Feedback_GNN(code=c, num_msg_dims=8, num_hidden_units=16, num_mlp_layers=3, reduce_op="max", activation="relu",
+                     use_bias=True, graph=gg)
+    assert not G.is_shipped_architecture and G.count_params() == sum(int(np.prod(a.shape)) for a in G.get_weights())
+    w = _gen_weights(cfg, seed=8)
+    w[1] = w[1] + 3.0  # keep the new channel LLRs in a sane range
+    G.set_weights(w)
+    with tempfile.TemporaryDirectory() as d:
+        save_weights(G, os.path.join(d, "g.npz"))
+        G2 = Feedback_GNN(code=c, num_msg_dims=8, num_hidden_units=16, num_mlp_layers=3, reduce_op="max", activation="relu",
+                          use_bias=True, graph=gg)
+        load_weights(G2, os.path.join(d, "g.npz"))
+        assert all(np.array_equal(a, b) for a, b in zip(G2.get_weights(), w))
+    with pytest.raises(ValueError):
+        Feedback_GNN(code=c, num_msg_dims=8, num_hidden_units=16, num_mlp_layers=3, reduce_op="median", graph=gg)
+    with pytest.raises(NotImplementedError):
+        Feedback_GNN(code=c, num_msg_dims=8, num_hidden_units=16, num_mlp_layers=3, activation="gelu", graph=gg)
+    d1 = QLDPCBPDecoder(code=c, num_iter=20, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True, graph=gg)
+    d2 = QLDPCBPDecoder(code=c, num_iter=8, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True, graph=gg)
+    m = Sandwich_BP_GNN_Evaluation_Model(c, [d1, d2], [G], num_layers=2, seed=SEED)
+    out = m.decode(B, p, first_sample=0)
+    ex, ez = og.pauli_noise(SEED, p, 0, B)
+    sx, sz = og.syndrome(ex, ez)
+    L0 = llr_const(0.05)
+    o1 = og.bp4_decode(sx, sz, 20, "boxplus-phi", 1.0, llr_const=L0)
+    rx, rz = og.syndrome(o1["x_hat"], o1["z_hat"])  # (hx z_hat, hz x_hat)
+    bad = (rx != sx).any(1) | (rz != sz).any(1)
+    new = og.feedback_gnn_general(_cfg_codes(cfg), w, o1["llr"], o1["z_logit"], o1["x_logit"], sx, sz)
+    o2 = og.bp4_decode(sx, sz, 8, "boxplus-phi", 1.0, llr_ch=new)
+    xh = np.where(bad[:, None], o2["x_hat"], o1["x_hat"])
+    zh = np.where(bad[:, None], o2["z_hat"], o1["z_hat"])
+    assert bad.sum() > 3
+    assert np.array_equal(out["x_hat"].cpu().numpy(), xh) and np.array_equal(out["z_hat"].cpu().numpy(), zh)
