@@ -134,3 +134,80 @@ class PlotBER:
             if add_bler:
                 self._bers.append(bler); self._snrs.append(ps); self._legends.append(legend + " (BLER)"); self._is_bler.append(True)
         return flagged, bler
+
+    # ---- the rest of the reference class' surface (plotting.py:207-310, :449-504): result bookkeeping and the figure ----
+    title = property(lambda self: self._title)
+
+    @title.setter
+    def title(self, value):
+        if not isinstance(value, str):
+            raise AssertionError("title must be string")
+        self._title = value
+
+    ber = property(lambda self: self._bers)
+    snr = property(lambda self: self._snrs)
+    legend = property(lambda self: self._legends)
+    is_bler = property(lambda self: self._is_bler)
+
+    def add(self, ebno_db, ber, is_bler=False, legend=""):
+        """Store an externally computed curve (x values, error rates)."""
+        if len(np.atleast_1d(ebno_db)) != len(np.atleast_1d(ber)):
+            raise AssertionError("ebno_db and ber must have same number of elements.")
+        if not isinstance(legend, str) or not isinstance(is_bler, bool):
+            raise AssertionError("legend must be str and is_bler must be bool.")
+        self._snrs.append(np.asarray(ebno_db, dtype=np.float64))
+        self._bers.append(np.asarray(ber, dtype=np.float64))
+        self._legends.append(legend)
+        self._is_bler.append(is_bler)
+
+    def reset(self):
+        self._bers, self._snrs, self._legends, self._is_bler = [], [], [], []
+
+    def remove(self, idx=-1):
+        if not isinstance(idx, int):
+            raise AssertionError("idx must be int.")
+        for store in (self._bers, self._snrs, self._legends, self._is_bler):
+            del store[idx]
+
+    def __call__(self, snr_db=(), ber=(), legend=(), is_bler=(), show_ber=True, show_bler=True, xlim=None, ylim=None,
+                 save_fig=False, path=""):
+        """Semilog-y figure of the stored curves plus the ones passed in (x axis: physical error rate p, which the reference
+        carries in its ``ebno_db`` argument).  Returns the matplotlib figure; ``save_fig`` writes it to ``path``."""
+        import matplotlib
+        if save_fig or not hasattr(matplotlib, "pyplot"):
+            matplotlib.use(matplotlib.get_backend() if "inline" in matplotlib.get_backend().lower() else "Agg", force=False)
+        import matplotlib.pyplot as plt
+
+        def as_list(x, n=None):
+            if isinstance(x, np.ndarray) or (len(x) and np.isscalar(x[0])):
+                x = [x]
+            x = list(x)
+            return x * n if n and len(x) == 1 and n > 1 else x
+
+        bers = self._bers + as_list(ber)
+        extra = len(bers) - len(self._bers)
+        snrs = self._snrs + as_list(snr_db, extra)
+        legends = self._legends + ([legend] if isinstance(legend, str) else list(legend))
+        flags = self._is_bler + ([is_bler] if isinstance(is_bler, bool) else list(is_bler))
+        legends += [""] * (len(bers) - len(legends))
+        flags += [False] * (len(bers) - len(flags))
+        keep = [i for i, f in enumerate(flags) if (f and show_bler) or (not f and show_ber)]
+        ylabel = "BLER" if keep and all(flags[i] for i in keep) else ("BER" if not any(flags[i] for i in keep) else "BER / BLER")
+        fig, ax = plt.subplots(figsize=(10, 6))
+        for i in keep:
+            ax.semilogy(np.asarray(snrs[i], dtype=np.float64), np.asarray(bers[i], dtype=np.float64), "--" if flags[i] else "-",
+                        marker="o", markersize=4, label=legends[i])
+        ax.set_title(self._title)
+        ax.set_xlabel("physical error rate p")
+        ax.set_ylabel(ylabel)
+        ax.grid(which="both", alpha=0.4)
+        if xlim is not None:
+            ax.set_xlim(xlim)
+        if ylim is not None:
+            ax.set_ylim(ylim)
+        if any(legends[i] for i in keep):
+            ax.legend()
+        if save_fig:
+            fig.savefig(path)
+        return fig
+

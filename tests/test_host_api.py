@@ -134,3 +134,27 @@ def test_training_helpers_on_cpu_tensors():
     b = torch.zeros((4, 5), dtype=torch.uint8)
     bh = b.clone(); bh[1, 2] = 1; bh[3, 0] = 1; bh[3, 4] = 1
     assert compute_bler(b, bh) == 0.5
+
+
+def test_plotber_bookkeeping_and_figure(tmp_path):
+    """PlotBER.add / remove / reset / properties / __call__ (sionna/utils/plotting.py:207-310, :449-504)."""
+    pytest.importorskip("matplotlib")
+    from feedback_gnn_amd.utils import PlotBER
+    pb = PlotBER("t")
+    pb.add([0.1, 0.09], [1e-2, 1e-3], is_bler=True, legend="a")
+    pb.add(np.array([0.1, 0.09]), np.array([2e-2, 3e-3]), legend="b")
+    assert pb.legend == ["a", "b"] and pb.is_bler == [True, False] and len(pb.ber) == 2 and len(pb.snr) == 2
+    pb.title = "u"
+    assert pb.title == "u"
+    with pytest.raises(AssertionError):
+        pb.add([0.1], [1e-2, 1e-3])
+    out = tmp_path / "fig.png"
+    fig = pb(snr_db=[0.1, 0.08], ber=[5e-2, 5e-4], legend="c", is_bler=True, ylim=(1e-5, 1), save_fig=True, path=str(out))
+    assert out.exists() and out.stat().st_size > 1000
+    assert len(fig.axes[0].lines) == 3 and fig.axes[0].get_ylabel() == "BER / BLER"
+    fig2 = pb(show_ber=False)
+    assert len(fig2.axes[0].lines) == 1 and fig2.axes[0].get_ylabel() == "BLER"
+    pb.remove(0)
+    assert pb.legend == ["b"]
+    pb.reset()
+    assert pb.ber == [] and pb.snr == []
