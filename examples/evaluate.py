@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Monte-Carlo evaluation of BP4 + feedback GNN on one MI355X — what `python n882.py -p P -id I` / `python n1270.py -nG N -p P -id I`
+do in the reference (n882.py:27-78, n1270.py:27-81), for either benchmark code.
+
+    python examples/evaluate.py --code ghp882 -nG 5 -p 0.05 -id 0
+    torchrun --nproc-per-node 8 examples/evaluate.py --code ghp1270 -nG 3 -p 0.06 --dist     # one rank per GPU, counters all-reduced
+
+Prints the reference's result table (p | Flagged | BLER | flag errors | block errors | num blocks | runtime | status).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--code", choices=["ghp882", "ghp1270"], default="ghp882")
+    ap.add_argument("-nG", "--num_G", type=int, default=5, help="Number of rounds of feedback.")
+    ap.add_argument("-p", "--p", type=float, nargs="+", default=[0.05], help="Physical error rate(s) p to simulate.")
+    ap.add_argument("-id", "--gpu_id", type=int, default=0, help="GPU id")
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--target", type=int, default=100, help="stop a point after this many logical errors")
+    ap.add_argument("--max-iter", type=int, default=100000)
+    ap.add_argument("--dist", action="store_true", help="one process per GPU under torchrun; sample stream sharded by rank")
+    args = ap.parse_args()
+
+    import torch
+    rank, world = 0, 1
+    if args.dist:
+        import torch.distributed as dist
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        torch.cuda.set_device(args.gpu_id)
+
+    import feedback_gnn_amd as F
+    if args.code == "ghp882":
+        code = F.create_QC_GHP_codes(63, F.create_cyclic_permuting_matrix(7, [27, 54, 0]), [0, 1, 6])  # 18 <= d <= 24
+        weights = "feedback_GNN_n882_k24_wt_4_60_iter_64_16_mixed.npz"
+    else:
+        code = F.create_QC_GHP_codes(127, np.array([[0, -1, 51, 52, -1], [-1, 0, -1, 111, 20], [0, -1, 98, -1, 122],
+                                                    [0, 80, -1, 119, -1], [-1, 0, 5, -1, 106]]), [0, 1, 7], name="GHP_n1270_k28")
+        weights = "feedback_GNN_n1270_k28_wt_10_80_iter_64_16_mixed.npz"
+    nG = args.num_G
+    if rank == 0:
+        print(f"Running {code.name} for {nG} rounds of GNN feedback at p={args.p} on {world} GPU(s).")
+    G = F.Feedback_GNN(code=code, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean", activation="tanh",
+                       use_bias=True)
+    F.load_weights(G, weights)
+    dec1 = F.QLDPCBPDecoder(code=code, num_iter=64, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True, graph=G.graph)
+    dec2 = F.QLDPCBPDecoder(code=code, num_iter=16, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True, graph=G.graph)
+    model = F.Sandwich_BP_GNN_Evaluation_Model(code, [dec1] + [dec2] * nG, [G] * nG, num_layers=nG + 1, compact=True,
+                                               rank=rank, world_size=world)
+    plot = F.PlotBER()
+    plot.simulate(model, ebno_dbs=args.p, batch_size=args.batch, num_target_block_errors=args.target,
+                  legend=f"feedback GNN 1.00 {nG} rounds", soft_estimates=True, max_mc_iter=args.max_iter, early_stop=True,
+                  add_bler=True, show_fig=False, qldpc=True, forward_keyboard_interrupt=False, dist=args.dist,
+                  verbose=(rank == 0))
+
+
+if __name__ == "__main__":
+    main()
