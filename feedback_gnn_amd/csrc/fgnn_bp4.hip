@@ -178,6 +178,30 @@ __device__ __forceinline__ bool cn_phi_regular(float* msg, const int (&sl)[DC], 
     return false;
 }
 
+// Runtime-degree phi rule with the exact saturation shortcut of cn_phi_regular: returns true when the whole wave took it.
+__device__ __forceinline__ bool cn_phi_generic(float* msg, const int* __restrict__ slot, int deg, unsigned synd, float factor,
+                                               float phi0, bool shortcut)
+{
+    if (shortcut) {
+        unsigned neg = synd;
+        bool sat = true;
+        for (int j = 0; j < deg; ++j) {
+            const float v = msg[slot[j]];
+            neg ^= (v < 0.0f);
+            sat = sat && (FG_ABS(v) >= FG_PHI_MAX);
+        }
+        if (__all(sat)) {
+            for (int j = 0; j < deg; ++j) {
+                const int s = slot[j];
+                msg[s] = with_sign(phi0, neg ^ (unsigned)(msg[s] < 0.0f)) * factor;
+            }
+            return true;
+        }
+    }
+    cn_update<FGNN_CN_BOXPLUS_PHI>(msg, slot, deg, synd, factor);
+    return false;
+}
+
 // tf2xla softplus for |t| > 13.94 only: identity above, exp(t) below (flushed under -87); same bits as fg_softplus there.
 __device__ __forceinline__ float softplus_saturated(float t)
 {
@@ -301,6 +325,38 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
                     const float Y = (Sz + Sx) + ly;
                     const float X = Sz + lx;
                     const float Z = Sx + lz;
+                    if (a.shortcut) {  // same exact shortcut (and sign words) as the regular path, runtime degrees
+                        bool sat = FG_ABS(X) > FG_SOFTPLUS_THRESH && FG_ABS(Z) > FG_SOFTPLUS_THRESH;
+                        unsigned sig = 0;
+                        for (int e = x0; e < x1; ++e) {
+                            const float mm = msg[e];
+                            sat = sat && (FG_ABS((Z - mm) - (Y - mm)) >= 20.0f);
+                            sig |= sign_bit(mm) << (e - x0);
+                        }
+                        for (int e = z0; e < z1; ++e) {
+                            const float mm = msg[e];
+                            sat = sat && (FG_ABS((X - mm) - (Y - mm)) >= 20.0f);
+                            sig |= sign_bit(mm) << ((x1 - x0) + (e - z0));
+                        }
+                        if (a.early_exit && sigw[v] != sig) {
+                            changed = true;
+                            sigw[v] = sig;
+                        }
+                        if (__all(sat)) {
+                            const float nx = softplus_saturated(-X), nz = softplus_saturated(-Z);
+                            for (int e = x0; e < x1; ++e) {
+                                const float mm = msg[e];
+                                const float Ze = Z - mm, Ye = Y - mm;
+                                msg[e] = nx - (0.0f + FG_MAX(-Ze, -Ye));
+                            }
+                            for (int e = z0; e < z1; ++e) {
+                                const float mm = msg[e];
+                                const float Xe = X - mm, Ye = Y - mm;
+                                msg[e] = nz - (0.0f + FG_MAX(-Xe, -Ye));
+                            }
+                            continue;
+                        }
+                    }
                     const float numx = fg_softplus(-X);
                     const float numz = fg_softplus(-Z);
                     for (int e = x0; e < x1; ++e) {
@@ -336,7 +392,9 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
                     else cn_update<CN_TYPE>(msg, sl, DC, synd, a.factor);
                 } else {
                     const int c0 = g.cptr[c], deg = g.cptr[c + 1] - c0;
-                    cn_update<CN_TYPE>(msg, g.cslot + c0, deg, synd, a.factor);
+                    if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI)
+                        cn_slow = !cn_phi_generic(msg, g.cslot + c0, deg, synd, a.factor, phi0, a.shortcut != 0) || cn_slow;
+                    else cn_update<CN_TYPE>(msg, g.cslot + c0, deg, synd, a.factor);
                 }
             }
         if (a.early_exit && cn_slow) flags[2 * (it & 1) + 1] = 1;
@@ -476,7 +534,9 @@ int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float n
     size_t lds_bytes = (size_t)per_cw * sizeof(float) * (size_t)L.cpb;
     const bool regular = g->d.cslot16 && !g->force_generic &&
                          ((g->d.dvx == 3 && g->d.dvz == 3 && g->d.dc == 6) || (g->d.dvx == 4 && g->d.dvz == 4 && g->d.dc == 8));
-    a.early_exit = (g->shortcut && g->early_exit && regular && cn_type == FGNN_CN_BOXPLUS_PHI && L.cpb == 1 && num_iter > 2) ? 1 : 0;
+    (void)regular;
+    a.early_exit = (g->shortcut && g->early_exit && g->d.max_vdeg <= 32 && cn_type == FGNN_CN_BOXPLUS_PHI && L.cpb == 1 &&
+                    num_iter > 2) ? 1 : 0;
     a.sig_off = per_cw;
     if (a.early_exit) {
         const size_t with_det = lds_bytes + ((size_t)g->d.n + 4) * sizeof(float);

@@ -162,6 +162,9 @@ extern "C" int fgnn_graph_create(int n, int m_x, int m_z, int nnz_x, const int32
     d.dvx = uniform_degree(vptr[0]);
     d.dvz = uniform_degree(vptr[1]);
     d.dc = uniform_degree(cptr);
+    d.max_vdeg = 0;
+    for (int v = 0; v < n; ++v)
+        d.max_vdeg = std::max(d.max_vdeg, (vptr[0][v + 1] - vptr[0][v]) + (vptr[1][v + 1] - vptr[1][v]));
     int rc;
     if (d.dvx > 0 && d.dvz > 0 && d.dc > 0 && d.dc <= 8 && d.E < 65536) {
         std::vector<uint16_t> pk((size_t)d.m * 8, 0);

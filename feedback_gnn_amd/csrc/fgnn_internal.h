@@ -29,6 +29,7 @@ struct GraphDev {
     const int* trow[2];  // [nnz]
     // uniform degrees, 0 if irregular
     int dvx, dvz, dc;
+    int max_vdeg;  // largest number of edges (both sides) at one qubit: the fixed-point detector packs one sign bit per edge
 };
 
 struct fgnn_graph {

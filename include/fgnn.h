@@ -63,12 +63,13 @@ int fgnn_graph_set_rows(fgnn_graph* g, int which, int rows, int nnz, const int32
 /* Launch geometry of the LDS-resident kernels: threads per codeword and codewords per workgroup.
  * 0 = keep the built-in heuristic.  (No reference equivalent: XLA picks its own launch shapes.) */
 int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords_per_block);
-/* Options.  FGNN_OPT_SATURATION_SHORTCUT (default 1): the degree-regular BP4 kernel skips the exp/log evaluation
+/* Options.  FGNN_OPT_SATURATION_SHORTCUT (default 1): the BP4 kernels (compile-time and runtime degrees) skip the exp/log evaluation
  * of a wave whose 64 nodes are all saturated (|v->c| >= 16.635532 at a check; totals beyond the softplus threshold
  * and 20 apart at a qubit), writing the values those evaluations produce bit for bit (phi(clip max) = 0,
  * phi(clip min), log(1) = 0).  Results are identical with 0 and 1; 0 evaluates every transcendental like the
  * reference's fixed dataflow (decoding_q.py:732-767) and is what bench.py's headline number uses.
- * FGNN_OPT_FIXED_POINT_EXIT (default 1, effective only with the shortcut on, boxplus-phi, one codeword per workgroup):
+ * FGNN_OPT_FIXED_POINT_EXIT (default 1, effective only with the shortcut on, boxplus-phi, one codeword per workgroup,
+ * at most 32 edges per qubit):
  * when two consecutive check-node phases were all-saturated and no c->v sign changed in between, the messages are at a
  * bit-exact fixed point of the (deterministic) iteration map, every remaining iteration is the identity, and the
  * workgroup leaves the loop.  Results are identical with 0 and 1. */

@@ -269,6 +269,41 @@ def test_fixed_point_exit_is_exact(name, p, iters, factor):
         gg.set_fixed_point_exit(True)
 
 
+@pytest.mark.parametrize("name,p,iters,factor,launch", [("ghp882", 0.02, 64, 1.0, "generic"), ("ghp882", 0.09, 40, 0.9, "generic"),
+                                                         ("gb254", 0.02, 64, 1.0, (256, 1)), ("gb254", 0.02, 64, 0.625, None),
+                                                         ("gb126", 0.02, 50, 0.8, (128, 1)), ("hp_c7", 0.02, 30, 1.0, (64, 1)),
+                                                         ("hp_c7", 0.02, 30, 1.0, None), ("gb48_oc", 0.02, 12, 1.0, (256, 1)),
+                                                         ("rsurf5", 0.03, 30, 1.0, None)])
+def test_exact_shortcuts_on_runtime_degree_graphs(name, p, iters, factor, launch):
+    """The saturation shortcut and the fixed-point exit in the CSR kernel (any degrees; the detector needs <= 32 edges per
+    qubit and one codeword per workgroup, otherwise only the shortcut acts): on, off, and against the oracle, bit for bit."""
+    B = 80
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, p, B, first=99)
+    gg = gpu_graph(name)
+    L0 = llr_const(0.1)
+    o = oracle_graph(name).bp4_decode(sx, sz, iters, "boxplus-phi", factor, llr_const=L0, return_msgs=True)
+    try:
+        if launch == "generic":
+            gg.force_generic(True)
+        elif launch is not None:
+            gg.set_launch(*launch)
+        for shortcut, fpe in ((True, True), (True, False), (False, False)):
+            gg.set_saturation_shortcut(shortcut)
+            gg.set_fixed_point_exit(fpe)
+            g = gg.bp4_decode(tx, tz, iters, "boxplus-phi", factor, llr_const=L0, return_msgs=True)
+            _assert_bp_equal(o, g, f"{name} shortcut={shortcut} exit={fpe}")
+        gg.set_saturation_shortcut(True)
+        gg.set_fixed_point_exit(True)
+        for cn in ("minsum", "boxplus"):  # the qubit-side shortcut also runs under the other rules
+            o2 = oracle_graph(name).bp4_decode(sx, sz, 12, cn, 0.8, llr_const=L0, return_msgs=True)
+            _assert_bp_equal(o2, gg.bp4_decode(tx, tz, 12, cn, 0.8, llr_const=L0, return_msgs=True), f"{name} {cn}")
+    finally:
+        gg.force_generic(False)
+        gg.set_launch(0, 0)
+        gg.set_saturation_shortcut(True)
+        gg.set_fixed_point_exit(True)
+
+
 def _gnnbp4_weights(seed=11):
     from feedback_gnn_amd.graph import GNNBP4_SHAPES
     rng = np.random.RandomState(seed)
