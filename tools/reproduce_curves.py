@@ -1,0 +1,87 @@
+"""Re-run the published logical-error-rate curves of the reference's notebooks (examples/n882.ipynb cells 2,3,5,6 and
+examples/n1270.ipynb cells 2,4,6,7,9) on one MI355X and compare row by row.
+
+For every published row (p, block errors, num blocks) the same model is simulated on `mult` x the published number of blocks
+(capped at `cap`), with all exact optimisations on (outputs identical to the fixed dataflow).  z = difference of the two rates
+in units of the combined binomial standard deviation; |z| < 4 on every row is the acceptance band of the GPU tests.
+usage: python tools/reproduce_curves.py [mult=4] [cap=250000000]  ->  gpurun_out/curves.json
+"""
+import json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from helpers import code as get_code
+import feedback_gnn_amd as F
+
+mult = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
+cap = int(float(sys.argv[2])) if len(sys.argv) > 2 else 250_000_000
+W = {"882": "feedback_GNN_n882_k24_wt_4_60_iter_64_16_mixed.npz", "1270": "feedback_GNN_n1270_k28_wt_10_80_iter_64_16_mixed.npz",
+     "1270c": "feedback_GNN_n1270_k28_wt_10_60_iter_16_16.npz"}
+# (label, code, weights, rounds of feedback, factor of the first decoder, [(p, block errors, num blocks), ...])
+CURVES = [
+    ("n882.ipynb cell 2: (64, [G,16]x3), factor 1.0", "ghp882", "882", 3, 1.0,
+     [(0.14, 2375, 5000), (0.13, 1162, 5000), (0.12, 396, 5000), (0.11, 185, 10000), (0.10, 113, 30000), (0.09, 100, 170000),
+      (0.08, 100, 1325000), (0.07, 100, 9475000), (0.06, 100, 45125000), (0.05, 100, 219050000)]),
+    ("n882.ipynb cell 3: (64, [G,16]x5), factor 1.0", "ghp882", "882", 5, 1.0,
+     [(0.14, 2371, 5000), (0.13, 1122, 5000), (0.12, 337, 5000), (0.11, 152, 10000), (0.10, 108, 45000), (0.09, 101, 380000),
+      (0.08, 100, 1935000), (0.07, 100, 11325000), (0.06, 100, 73275000), (0.05, 19, 100000000), (0.04, 8, 100000000)]),
+    ("n882.ipynb cell 5: (64, [G,16]x3), factor 0.8", "ghp882", "882", 3, 0.8,
+     [(0.14, 1701, 5000), (0.13, 697, 5000), (0.12, 195, 5000), (0.11, 131, 15000), (0.10, 108, 65000), (0.09, 100, 325000),
+      (0.08, 100, 1640000), (0.07, 100, 7855000)]),
+    ("n882.ipynb cell 6: (64, [G,16]x5), factor 0.8", "ghp882", "882", 5, 0.8,
+     [(0.14, 1652, 5000), (0.13, 668, 5000), (0.12, 184, 5000), (0.11, 123, 15000), (0.10, 104, 75000), (0.09, 101, 415000),
+      (0.08, 100, 1705000), (0.07, 100, 9825000)]),
+    ("n1270.ipynb cell 2: (64, [G,16]x3), factor 1.0", "ghp1270", "1270", 3, 1.0,
+     [(0.14, 1986, 5000), (0.13, 705, 5000), (0.12, 139, 5000), (0.11, 106, 25000), (0.10, 100, 275000), (0.09, 100, 2795000),
+      (0.08, 100, 17335000), (0.07, 100, 80890000)]),
+    ("n1270.ipynb cell 4: (64, [G,16]x5), factor 1.0", "ghp1270", "1270", 5, 1.0,
+     [(0.14, 1827, 5000), (0.13, 570, 5000), (0.12, 111, 5000), (0.11, 117, 40000), (0.10, 101, 490000), (0.09, 100, 5475000),
+      (0.08, 100, 35335000)]),
+    ("n1270.ipynb cell 6: (64, [G,16]x3), factor 0.8", "ghp1270", "1270", 3, 0.8,
+     [(0.14, 1230, 5000), (0.13, 327, 5000), (0.12, 122, 15000), (0.11, 100, 140000), (0.10, 101, 740000), (0.09, 100, 3000000)]),
+    ("n1270.ipynb cell 7: (64, [G,16]x5), factor 0.8", "ghp1270", "1270", 5, 0.8,
+     [(0.14, 1139, 5000), (0.13, 274, 5000), (0.12, 112, 15000), (0.11, 103, 145000), (0.10, 101, 925000), (0.09, 100, 3785000)]),
+    ("n1270.ipynb cell 9: (64, G_coarse, 16), factor 1.0", "ghp1270", "1270c", 1, 1.0,
+     [(0.14, 2333, 5000), (0.13, 1053, 5000), (0.12, 365, 5000), (0.11, 129, 5000), (0.10, 107, 15000), (0.09, 102, 40000),
+      (0.08, 102, 75000), (0.07, 106, 150000), (0.06, 101, 270000), (0.05, 100, 560000), (0.04, 100, 1165000),
+      (0.03, 100, 1710000), (0.02, 100, 5080000)]),
+]
+graphs, out, T0 = {}, [], time.time()
+total = 0
+for label, cname, wkey, nG, f1, rows in CURVES:
+    c = get_code(cname)
+    if cname not in graphs:
+        graphs[cname] = F.TannerGraph(c)
+    g = graphs[cname]
+    G = F.Feedback_GNN(code=c, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean", activation="tanh",
+                       use_bias=True, graph=g)
+    F.load_weights(G, W[wkey])
+    d1 = F.QLDPCBPDecoder(code=c, num_iter=64, normalization_factor=f1, cn_type="boxplus-phi", stage_one=True, graph=g)
+    d2 = F.QLDPCBPDecoder(code=c, num_iter=16, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True, graph=g)
+    model = F.Sandwich_BP_GNN_Evaluation_Model(c, [d1] + [d2] * nG, [G] * nG, num_layers=nG + 1, compact=True, seed=0xC0FFEE)
+    print(f"\n{label}\n{'p':>6} | {'published':>26} | {'this run':>30} | {'z':>6} | {'time':>7}", flush=True)
+    res = []
+    for p, pub_err, pub_n in rows:
+        n = int(min(cap, max(mult * pub_n, 65536)))
+        B = 65536 if n >= 65536 else n
+        counts = torch.zeros(3, dtype=torch.int64, device=g.device)
+        torch.cuda.synchronize(); t0 = time.time()
+        done = 0
+        while done < n:
+            b = min(B, n - done)
+            model.mc_step(b, p, counts)
+            done += b
+        fl, bl, tot = [int(v) for v in counts.cpu()]
+        dt = time.time() - t0
+        total += tot
+        r_pub, r = pub_err / pub_n, bl / tot
+        pooled = (pub_err + bl) / (pub_n + tot)
+        z = (r - r_pub) / max(np.sqrt(pooled * (1 - pooled) * (1 / pub_n + 1 / tot)), 1e-300)
+        res.append(dict(p=p, published_errors=pub_err, published_blocks=pub_n, errors=bl, flagged=fl, blocks=tot, z=float(z), seconds=dt))
+        print(f"{p:6.2f} | {pub_err:6d}/{pub_n:<10d} {r_pub:9.3e} | {bl:8d}/{tot:<11d} {r:9.3e} | {z:6.2f} | {dt:6.1f}s", flush=True)
+    out.append(dict(curve=label, rows=res))
+zs = np.array([r["z"] for cv in out for r in cv["rows"]])
+summary = dict(rows=int(zs.size), max_abs_z=float(np.abs(zs).max()), mean_z=float(zs.mean()), rms_z=float(np.sqrt((zs ** 2).mean())),
+               total_blocks=int(total), seconds=time.time() - T0)
+print("\nsummary:", summary)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(dict(mult=mult, cap=cap, summary=summary, curves=out), open("gpurun_out/curves.json", "w"), indent=1)
