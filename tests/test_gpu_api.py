@@ -88,8 +88,10 @@ def test_feedback_gnn_class_and_weights():
     assert out.shape == (B, c.N, 3)
     ref = og.feedback_gnn(w, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
     assert np.array_equal(ref.transpose(0, 2, 1), out.cpu().numpy())
-    with pytest.raises(NotImplementedError):
-        F.Feedback_GNN(code=c, num_msg_dims=16, num_hidden_units=40, num_mlp_layers=2, use_bias=True)
+    G16 = F.Feedback_GNN(code=c, num_msg_dims=16, num_hidden_units=40, num_mlp_layers=2, use_bias=True, graph=G.graph)
+    assert not G16.is_shipped_architecture and G16.count_params() == 40 * 3 + 3 + 2 * (4 * 40 + 40 + 40 * 16 + 16) + 35 * 40 + 40
+    with pytest.raises(NotImplementedError):  # beyond the runtime-shaped kernel's limits
+        F.Feedback_GNN(code=c, num_msg_dims=64, num_hidden_units=40, num_mlp_layers=2, use_bias=True, graph=G.graph)
 
 
 def _model(c, iters, compact=False, **kw):
