@@ -212,10 +212,14 @@ __device__ __forceinline__ float softplus_saturated(float t)
 // DVX/DVZ/DC > 0: every qubit has exactly DVX hx-edges and DVZ hz-edges and every check DC edges, so a
 // qubit's slots are v*DVX+k / E_x+v*DVZ+k (no index loads) and a check's DC slots come as one packed
 // 16-byte row of g.cslot16.  DVX = 0: runtime degrees through the CSR tables.
-template <int CN_TYPE, int DVX, int DVZ, int DC>
-__global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
+// OPT = false compiles the exact optimisations (saturation shortcut, fixed-point detector) out: the fixed-dataflow
+// variant bench.py's headline times carries none of their tests.
+template <int CN_TYPE, int DVX, int DVZ, int DC, bool OPT>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) bp4_kernel(GraphDev g, BpArgs a)
 {
     constexpr bool REGULAR = DVX > 0;
+    const bool opt_shortcut = OPT && a.shortcut != 0;
+    const bool opt_exit = OPT && a.early_exit != 0;
     extern __shared__ float lds[];
     const int cwl = threadIdx.x / a.tpc;
     const int lane = threadIdx.x - cwl * a.tpc;
@@ -247,7 +251,7 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
     unsigned* sigw = reinterpret_cast<unsigned*>(msg + a.sig_off);  // [n] sign words, then 2 x {changed, cn_slow}
     int* flags = reinterpret_cast<int*>(sigw + n);
     bool a1 = false, a2 = false;
-    if (a.early_exit) {
+    if (opt_exit) {
         for (int v = lane; v < n; v += a.tpc) sigw[v] = 0xffffffffu;
         if (lane < 4) flags[lane] = 0;
         __syncthreads();
@@ -269,7 +273,7 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
                     for (int k = 0; k < DVZ; ++k) { mz[k] = pz[k]; Sz = Sz + mz[k]; }
 #pragma unroll
                     for (int k = 0; k < DVX; ++k) { mx[k] = px[k]; Sx = Sx + mx[k]; }
-                    if (a.early_exit) {
+                    if (opt_exit) {
                         unsigned sig = 0;
 #pragma unroll
                         for (int k = 0; k < DVX; ++k) sig |= sign_bit(mx[k]) << k;
@@ -285,12 +289,12 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
                     const float Z = Sx + lz;
                     // Saturation shortcut (exact): |X|,|Z| beyond the softplus thresholds and every pair (Z_e,Y_e) /
                     // (X_e,Y_e) at least 20 apart => log(1+exp(-d)) is log(1) = 0 bit for bit and lse2 returns its max.
-                    bool sat = a.shortcut && FG_ABS(X) > FG_SOFTPLUS_THRESH && FG_ABS(Z) > FG_SOFTPLUS_THRESH;
+                    bool sat = opt_shortcut && FG_ABS(X) > FG_SOFTPLUS_THRESH && FG_ABS(Z) > FG_SOFTPLUS_THRESH;
 #pragma unroll
                     for (int k = 0; k < DVX; ++k) sat = sat && (FG_ABS((Z - mx[k]) - (Y - mx[k])) >= 20.0f);
 #pragma unroll
                     for (int k = 0; k < DVZ; ++k) sat = sat && (FG_ABS((X - mz[k]) - (Y - mz[k])) >= 20.0f);
-                    if (a.shortcut && __all(sat)) {
+                    if (opt_shortcut && __all(sat)) {
                         const float numx = softplus_saturated(-X);
                         const float numz = softplus_saturated(-Z);
 #pragma unroll
@@ -325,7 +329,7 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
                     const float Y = (Sz + Sx) + ly;
                     const float X = Sz + lx;
                     const float Z = Sx + lz;
-                    if (a.shortcut) {  // same exact shortcut (and sign words) as the regular path, runtime degrees
+                    if (opt_shortcut) {  // same exact shortcut (and sign words) as the regular path, runtime degrees
                         bool sat = FG_ABS(X) > FG_SOFTPLUS_THRESH && FG_ABS(Z) > FG_SOFTPLUS_THRESH;
                         unsigned sig = 0;
                         for (int e = x0; e < x1; ++e) {
@@ -338,7 +342,7 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
                             sat = sat && (FG_ABS((X - mm) - (Y - mm)) >= 20.0f);
                             sig |= sign_bit(mm) << ((x1 - x0) + (e - z0));
                         }
-                        if (a.early_exit && sigw[v] != sig) {
+                        if (opt_exit && sigw[v] != sig) {
                             changed = true;
                             sigw[v] = sig;
                         }
@@ -371,10 +375,10 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
                     }
                 }
             }
-        if (a.early_exit && changed) flags[2 * (it & 1)] = 1;
+        if (opt_exit && changed) flags[2 * (it & 1)] = 1;
         __syncthreads();
         // ---- check nodes of both graphs (:752-767) ----
-        if (a.early_exit && lane == 0) {  // clear the other parity's flags: nobody reads or sets them during this phase
+        if (opt_exit && lane == 0) {  // clear the other parity's flags: nobody reads or sets them during this phase
             flags[2 * ((it + 1) & 1)] = 0;
             flags[2 * ((it + 1) & 1) + 1] = 0;
         }
@@ -388,18 +392,18 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
 #pragma unroll
                     for (int j = 0; j < DC; ++j) sl[j] = (int)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
                     if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI)
-                        cn_slow = !cn_phi_regular<DC>(msg, sl, synd, a.factor, phi0, a.shortcut != 0) || cn_slow;
+                        cn_slow = !cn_phi_regular<DC>(msg, sl, synd, a.factor, phi0, opt_shortcut) || cn_slow;
                     else cn_update<CN_TYPE>(msg, sl, DC, synd, a.factor);
                 } else {
                     const int c0 = g.cptr[c], deg = g.cptr[c + 1] - c0;
                     if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI)
-                        cn_slow = !cn_phi_generic(msg, g.cslot + c0, deg, synd, a.factor, phi0, a.shortcut != 0) || cn_slow;
+                        cn_slow = !cn_phi_generic(msg, g.cslot + c0, deg, synd, a.factor, phi0, opt_shortcut) || cn_slow;
                     else cn_update<CN_TYPE>(msg, g.cslot + c0, deg, synd, a.factor);
                 }
             }
-        if (a.early_exit && cn_slow) flags[2 * (it & 1) + 1] = 1;
+        if (opt_exit && cn_slow) flags[2 * (it & 1) + 1] = 1;
         __syncthreads();
-        if (a.early_exit) {
+        if (opt_exit) {
             const bool stable = a1 && a2 && flags[2 * (it & 1)] == 0;
             a2 = a1;
             a1 = flags[2 * (it & 1) + 1] == 0;
@@ -469,7 +473,7 @@ __global__ void __launch_bounds__(1024) bp4_kernel(GraphDev g, BpArgs a)
 template <int CN_TYPE, int DVX, int DVZ, int DC>
 int launch_bp4_k(const fgnn_graph* g, const BpArgs& a, const LaunchGeom& L, size_t lds_bytes, hipStream_t st)
 {
-    auto kern = bp4_kernel<CN_TYPE, DVX, DVZ, DC>;
+    auto kern = a.shortcut ? bp4_kernel<CN_TYPE, DVX, DVZ, DC, true> : bp4_kernel<CN_TYPE, DVX, DVZ, DC, false>;
     if (lds_bytes > 48 * 1024)
         FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes));

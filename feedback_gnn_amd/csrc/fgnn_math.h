@@ -26,6 +26,12 @@
 #define FG_MAX(a, b) __builtin_fmaxf((a), (b))
 #define FG_MIN(a, b) __builtin_fminf((a), (b))
 #define FG_ABS(a) __builtin_fabsf((a))
+/* clamp to [lo, hi], lo <= hi, no NaNs: one v_med3_f32 (fmaxf/fminf would first canonicalise the operand: one extra VALU op) */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FG_CLAMP(x, lo, hi) __builtin_amdgcn_fmed3f((x), (lo), (hi))
+#else
+#define FG_CLAMP(x, lo, hi) FG_MIN(FG_MAX((x), (lo)), (hi))
+#endif
 FG_FN uint32_t fg_f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 FG_FN float fg_u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
 #else
@@ -36,6 +42,7 @@ FG_FN float fg_u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
 #define FG_MAX(a, b) (((a) > (b)) ? (a) : (b))
 #define FG_MIN(a, b) (((a) < (b)) ? (a) : (b))
 #define FG_ABS(a) __builtin_fabsf((a))
+#define FG_CLAMP(x, lo, hi) FG_MIN(FG_MAX((x), (lo)), (hi))
 FG_FN uint32_t fg_f2u(float x) { union { float f; uint32_t u; } c; c.f = x; return c.u; }
 FG_FN float fg_u2f(uint32_t x) { union { float f; uint32_t u; } c; c.u = x; return c.f; }
 #endif
@@ -126,7 +133,7 @@ FG_FN float fg_log1p(float u)
  * log1p(exp(t)), thr = log(eps)+2.  exp underflow (t < -87) is flushed to 0. */
 FG_FN float fg_softplus(float t)
 {
-    float tc = FG_MIN(FG_MAX(t, -87.0f), FG_SOFTPLUS_THRESH);
+    float tc = FG_CLAMP(t, -87.0f, FG_SOFTPLUS_THRESH);
     float y = fg_exp(tc);
     float l = fg_log1p(y);
     float small = (t < -87.0f) ? 0.0f : y;
@@ -148,7 +155,7 @@ FG_FN float fg_lse2(float a, float b)
  *   x = clip(x, 8.5e-8, 16.635532); softplus(x) - log(exp(x) - 1). */
 FG_FN float fg_phi(float x)
 {
-    float xc = FG_MIN(FG_MAX(x, FG_PHI_MIN), FG_PHI_MAX);
+    float xc = FG_CLAMP(x, FG_PHI_MIN, FG_PHI_MAX);
     float y = fg_exp(xc);
     float sp = fg_log1p(y);
     sp = (xc > FG_SOFTPLUS_THRESH) ? xc : sp;
@@ -158,7 +165,7 @@ FG_FN float fg_phi(float x)
 /* GNN_BP4._phi, sionna/fec/ldpc/gnn.py:333-338: same clip, but log(exp(x)+1) - log(exp(x)-1) (no softplus). */
 FG_FN float fg_phi_gnn(float x)
 {
-    float xc = FG_MIN(FG_MAX(x, FG_PHI_MIN), FG_PHI_MAX);
+    float xc = FG_CLAMP(x, FG_PHI_MIN, FG_PHI_MAX);
     float y = fg_exp(xc);
     return fg_log(y + 1.0f) - fg_log(y - 1.0f);
 }

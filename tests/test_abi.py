@@ -42,3 +42,33 @@ def test_argument_errors_cross_the_abi_as_codes():
 def test_no_torch_types_in_the_abi():
     text = open(os.path.join(ROOT, "include", "fgnn.h")).read()
     assert "torch" not in text.lower() and "at::" not in text and "#include <hip" not in text
+
+
+def _abi_host():
+    import __graft_entry__ as entry
+    return entry.build_abi_host()
+
+
+def test_cpp_host_builds_the_same_graph_as_the_package():
+    """tests/abi_host.cpp restates the QC-GHP construction in C++ (it must not depend on Python): same edge lists as codes_q."""
+    import subprocess
+    import numpy as np
+    from helpers import code
+    out = subprocess.run([_abi_host(), "--graph"], stdout=subprocess.PIPE, text=True, check=True).stdout.split()
+    c = code("ghp882")
+    h = 0
+    for tag, mat in ((0x1111, c.hx), (0x2222, c.hz)):
+        r, col = np.nonzero(np.asarray(mat))
+        for a, b in zip(r.tolist(), col.tolist()):
+            h = (h + ((a * 2654435761 + b) ^ tag)) % (1 << 64)
+    assert [int(x) for x in out] == [882, 441, 2646, h]
+
+
+@pytest.mark.gpu
+def test_c_abi_from_a_plain_cpp_host_matches_the_oracle():
+    """The drop-in boundary without Python or torch: a C++ program hipMallocs its own buffers, creates its own stream and calls
+    fgnn_graph_create / set_rows / weights_create / pauli_noise / syndrome / bp4_decode / sandwich_decode / flag_update; every
+    output equals the oracle's C entry points bit for bit (tests/abi_host.cpp)."""
+    import subprocess
+    res = subprocess.run([_abi_host(), "128", "0.10"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0 and "abi_host ok" in res.stdout, res.stdout

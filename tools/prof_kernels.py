@@ -1,5 +1,6 @@
 """Launch each hot kernel a few times at the benchmark shape (for rocprofv3 --kernel-trace / --pmc passes).
-    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU ... -d out -- python3 tools/prof_kernels.py [code] [B]"""
+    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU ... -d out -- python3 tools/prof_kernels.py [code] [B] [fixed|product]
+`fixed` (default) switches the exact shortcuts off, like bench.py's headline: every exp/log of every iteration is evaluated."""
 import sys
 import torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -9,6 +10,7 @@ from feedback_gnn_amd.weights_io import read_weight_list
 name = sys.argv[1] if len(sys.argv) > 1 else 'ghp882'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 g = TannerGraph(code(name))
+g.set_saturation_shortcut(len(sys.argv) > 3 and sys.argv[3] == 'product')
 ex, ez = g.pauli_noise(0x5EED, 0.01, 0, B)
 sx, sz = g.syndrome(ex, ez)
 L0 = llr_const(0.05)
