@@ -107,8 +107,10 @@ extern "C" int fgnn_sandwich_decode(const fgnn_graph* g, int num_layers, const i
     const int n = g->d.n;
     int rc;
     // decoders[0] on the constant channel LLR (feedback_gnn.py:311-313,321)
+    const bool only = num_layers == 1;  // no feedback round: nobody reads the soft syndromes
     rc = fgnn_bp4_decode_impl(g, cn_types[0], iters[0], factors[0], nullptr, llr_const, synd_x, synd_z, B, nullptr, nullptr,
-                              ws.llr_a, x_hat, z_hat, ws.xlogit, ws.zlogit, nullptr, nullptr, nullptr, stream);
+                              ws.llr_a, x_hat, z_hat, only ? nullptr : ws.xlogit, only ? nullptr : ws.zlogit, nullptr, nullptr,
+                              nullptr, stream);
     if (rc) return rc;
     const int blk = (B + 255) / 256;
     if (num_layers > 1) hipLaunchKernelGGL(fill_u8, dim3(blk), dim3(256), 0, st, ws.errors, (uint8_t)1, B);  // (:322)
@@ -133,8 +135,12 @@ extern "C" int fgnn_sandwich_decode(const fgnn_graph* g, int num_layers, const i
         rc = fgnn_feedback_gnn_impl(g, weights[i - 1], ws.llr_a, ws.zlogit, ws.xlogit, synd_x, synd_z, nact, ws.llr_b, index,
                                     stream);
         if (rc) return rc;
+        // the soft syndromes of the LAST decoder feed nothing (:336-340 use only x_hat, z_hat): not computed, as XLA drops
+        // the unused outputs of the reference's jit-compiled call
+        const bool last = i == num_layers - 1;
         rc = fgnn_bp4_decode_impl(g, cn_types[i], iters[i], factors[i], ws.llr_b, 0.0f, synd_x, synd_z, nact, nullptr, nullptr,
-                                  ws.llr_a, ws.x_upd, ws.z_upd, ws.xlogit, ws.zlogit, nullptr, nullptr, index, stream);  // (:336)
+                                  ws.llr_a, ws.x_upd, ws.z_upd, last ? nullptr : ws.xlogit, last ? nullptr : ws.zlogit, nullptr,
+                                  nullptr, index, stream);  // (:336)
         if (rc) return rc;
         rc = fgnn_merge(ws.errors, ws.x_upd, ws.z_upd, B, n, x_hat, z_hat, stream);  // (:339-340)
         if (rc) return rc;

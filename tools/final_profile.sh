@@ -1,0 +1,22 @@
+#!/bin/bash
+# One gpurun call that produces everything profiles/ cites for a round:  bash tools/final_profile.sh <tag>
+# (GPU tests, bench line, rocprofv3 kernel trace of the same bench command, PMC passes on the fixed-dataflow kernels)
+set -e
+TAG=${1:-r00}
+O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $O
+cd $GRAFT_REPO_ROOT
+python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1 || { tail -30 $O/pytest_gpu.log; exit 1; }
+tail -2 $O/pytest_gpu.log
+python bench.py > $O/bench.json 2> $O/bench.err
+cat $O/bench.json
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-extras > $O/trace_bench.json 2>&1
+for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_WAIT_INST_LDS"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $O/pmc_$tag -- python3 tools/prof_kernels.py ghp882 65536 fixed > $O/pmc_$tag.log 2>&1
+done
+python tools/pmc_summary.py $O/pmc_*/*/*_counter_collection.csv > $O/pmc_summary.txt
+python tools/dispatch_summary.py $O/trace/*/*_kernel_trace.csv > $O/dispatches.txt
+cat $O/dispatches.txt
+grep -E "bp4_kernel.*b12 (FETCH|WRITE|SQ_INSTS_VALU |GRBM)" $O/pmc_summary.txt
