@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) 
 
     const uint8_t* sx = a.synd_x + (size_t)b * g.m_x;
     const uint8_t* sz = a.synd_z + (size_t)b * g.m_z;
+    const int lane_c = lane + (a.tpc >> 1) < a.tpc ? lane + (a.tpc >> 1) : lane - a.tpc + (a.tpc >> 1);
 
     const float phi0 = fg_phi(0.0f);  // = phi(clip min) = 16.6355324, the saturated message magnitude
     (void)phi0;
@@ -382,8 +383,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) 
             flags[2 * ((it + 1) & 1)] = 0;
             flags[2 * ((it + 1) & 1) + 1] = 0;
         }
+        // checks are dealt to the threads half a workgroup out of phase with the qubits: with 882 nodes on 4 waves two waves get
+        // 4 slices of 64 and two get 3 — the qubit phase gives the extra slice to the low waves, the check phase to the high ones
         if (active)
-            for (int c = lane; c < g.m; c += a.tpc) {
+            for (int c = lane_c; c < g.m; c += a.tpc) {
                 const unsigned synd = (c < g.m_x ? sx[c] : sz[c - g.m_x]) & 1u;
                 if constexpr (REGULAR) {
                     const uint4 pk = reinterpret_cast<const uint4*>(g.cslot16)[c];

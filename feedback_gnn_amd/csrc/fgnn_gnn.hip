@@ -112,25 +112,32 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-template <int DV>
-__global__ void __launch_bounds__(256, 4) gnn_mfma_kernel(GraphDev g, WeightsDev w, GnnArgs a)
+// CPB codewords per workgroup, four waves each: the 34 KB of operand tables are shared, so LDS no longer caps the CU at four
+// workgroups of four waves — with CPB = 4 two 16-wave workgroups fill all 8 wave slots of every SIMD.
+template <int DV, int CPB>
+__global__ void __launch_bounds__(256 * CPB) gnn_mfma_kernel(GraphDev g, WeightsDev w, GnnArgs a)
 {
     extern __shared__ float lds[];
-    const int slot_b = blockIdx.x;
-    const int b = a.index ? a.index[slot_b] : slot_b;
-    // LDS: the per-lane operand tables [T_COUNT][64] (shared by the 4 waves; one conflict-free ds_read_b32 per
-    // MFMA keeps ~130 registers free, which buys 4 waves per SIMD instead of 2), then g_x | g_z  (:168-172)
+    const int cwl = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const int slot_b = blockIdx.x * CPB + cwl;
+    const bool active = slot_b < a.B;
+    const int b = (active && a.index) ? a.index[slot_b] : slot_b;
+    // LDS: the per-lane operand tables [T_COUNT][64] (shared by all waves; one conflict-free ds_read_b32 per
+    // MFMA keeps ~130 registers free), then per codeword g_x | g_z  (:168-172)
     float* tabs = lds;
-    float* gcn = lds + T_COUNT * 64;
+    float* gcn = lds + T_COUNT * 64 + cwl * a.lds_per_cw;
     const int n = g.n;
-    for (int i = threadIdx.x; i < T_COUNT * 64; i += 256) tabs[i] = w.lane_tab[i];
-    for (int c = threadIdx.x; c < g.m_x; c += 256)
-        gcn[c] = a.logit_hx[(size_t)b * g.m_x + c] * ((a.synd_x[(size_t)b * g.m_x + c] & 1) ? -1.0f : 1.0f);
-    for (int c = threadIdx.x; c < g.m_z; c += 256)
-        gcn[g.m_x + c] = a.logit_hz[(size_t)b * g.m_z + c] * ((a.synd_z[(size_t)b * g.m_z + c] & 1) ? -1.0f : 1.0f);
+    for (int i = threadIdx.x; i < T_COUNT * 64; i += 256 * CPB) tabs[i] = w.lane_tab[i];
+    if (active) {
+        for (int c = tid; c < g.m_x; c += 256)
+            gcn[c] = a.logit_hx[(size_t)b * g.m_x + c] * ((a.synd_x[(size_t)b * g.m_x + c] & 1) ? -1.0f : 1.0f);
+        for (int c = tid; c < g.m_z; c += 256)
+            gcn[g.m_x + c] = a.logit_hz[(size_t)b * g.m_z + c] * ((a.synd_z[(size_t)b * g.m_z + c] & 1) ? -1.0f : 1.0f);
+    }
     __syncthreads();
+    if (!active) return;
 
-    const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = threadIdx.x & 63, wave = tid >> 6;
     const int j = l & 15, q = l >> 4;
 #define TAB(e) tabs[toff + (e) * 64]
     // the asm statements make the table OFFSET opaque per use site: hipcc would otherwise hoist all 132
@@ -578,9 +585,15 @@ int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const flo
         return FGNN_OK;
     }
     if (g->d.dvx == 3 && g->d.dvz == 3 && !g->force_generic) {
-        // degree-regular graph: MFMA kernel, one codeword per 256-thread workgroup
-        hipLaunchKernelGGL(gnn_mfma_kernel<3>, dim3(B), dim3(256), (size_t)(T_COUNT * 64 + a.lds_per_cw) * sizeof(float),
-                           static_cast<hipStream_t>(stream), g->d, w->d, a);
+        // degree-regular graph: MFMA kernel, four waves per codeword, GNN_CPB codewords per workgroup
+        constexpr int GNN_CPB = 4;
+        const size_t lds_mfma = (size_t)(T_COUNT * 64 + GNN_CPB * a.lds_per_cw) * sizeof(float);
+        auto kern = gnn_mfma_kernel<3, GNN_CPB>;
+        if (lds_mfma > 48 * 1024)
+            FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds_mfma));
+        hipLaunchKernelGGL(kern, dim3((B + GNN_CPB - 1) / GNN_CPB), dim3(256 * GNN_CPB), lds_mfma, static_cast<hipStream_t>(stream),
+                           g->d, w->d, a);
         FGNN_HIP_CHECK(hipGetLastError());
         return FGNN_OK;
     }
