@@ -230,7 +230,11 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) 
     float* Lch = msg + a.lch_off;  // [3n], only when llr_ch != null
     const int n = g.n;
 
-    if (active) {
+    // Closed-form first iteration (exact; product default only): with zero initial messages and one constant channel LLR every
+    // qubit sends the same v->c value in iteration 0, so a check's six outputs differ by the syndrome sign alone.
+    const bool first_closed = OPT && REGULAR && CN_TYPE == FGNN_CN_BOXPLUS_PHI && opt_shortcut && !a.llr_ch && !a.msg_init_x &&
+                              !a.msg_init_z && a.num_iter > 0;
+    if (active && !first_closed) {
         for (int e = lane; e < g.E_x; e += a.tpc) msg[e] = a.msg_init_x ? a.msg_init_x[(size_t)b * g.E_x + e] : 0.0f;
         for (int e = lane; e < g.E_z; e += a.tpc)
             msg[g.E_x + e] = a.msg_init_z ? a.msg_init_z[(size_t)b * g.E_z + e] : 0.0f;
@@ -253,11 +257,45 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) 
     int* flags = reinterpret_cast<int*>(sigw + n);
     bool a1 = false, a2 = false;
     if (opt_exit) {
-        for (int v = lane; v < n; v += a.tpc) sigw[v] = 0xffffffffu;
+        // (closed-form start: the sign words iteration 0 would have recorded are those of the all-zero messages)
+        for (int v = lane; v < n; v += a.tpc) sigw[v] = first_closed ? 0u : 0xffffffffu;
         if (lane < 4) flags[lane] = 0;
         __syncthreads();
     }
-    for (int it = 0; it < a.num_iter; ++it) {
+    int it_begin = 0;
+    if constexpr (OPT && REGULAR && CN_TYPE == FGNN_CN_BOXPLUS_PHI) {
+        if (first_closed) {
+            // the float operations of iteration 0, evaluated once per thread instead of once per edge: totals of zero messages
+            // (:244-248), v->c (:254-273), then the phi rule on six equal inputs (:376-431) in the summation order of cn_phi_regular
+            const float L = a.llr_const;
+            const float Y = (0.0f + 0.0f) + L, X = 0.0f + L, Z = 0.0f + L;
+            const float nu_x = fg_softplus(-X) - fg_lse2(-(Z - 0.0f), -(Y - 0.0f));
+            const float nu_z = fg_softplus(-Z) - fg_lse2(-(X - 0.0f), -(Y - 0.0f));
+            if (active)
+                for (int c = lane_c; c < g.m; c += a.tpc) {
+                    const unsigned synd = (c < g.m_x ? sx[c] : sz[c - g.m_x]) & 1u;
+                    const uint4 pk = reinterpret_cast<const uint4*>(g.cslot16)[c];
+                    const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
+                    const float nu = c < g.m_x ? nu_x : nu_z;
+                    const unsigned ng = nu < 0.0f;
+                    unsigned neg = synd;
+                    const float aa = fg_phi(FG_ABS(nu));
+                    float T = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) {
+                        neg ^= ng;
+                        T = T + aa;
+                    }
+                    const float val = with_sign(fg_phi(T - aa), neg ^ ng) * a.factor;
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) msg[(int)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu)] = val;
+                }
+            a1 = FG_ABS(nu_x) >= FG_PHI_MAX && FG_ABS(nu_z) >= FG_PHI_MAX;  // "iteration 0's check phase was all-saturated"
+            it_begin = 1;
+            __syncthreads();
+        }
+    }
+    for (int it = it_begin; it < a.num_iter; ++it) {
         bool changed = false, cn_slow = false;
         // ---- variable nodes: _vn_update (:227-275) ----
         if (active)

@@ -66,7 +66,9 @@ int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords
 /* Options.  FGNN_OPT_SATURATION_SHORTCUT (default 1): the BP4 kernels (compile-time and runtime degrees) skip the exp/log evaluation
  * of a wave whose 64 nodes are all saturated (|v->c| >= 16.635532 at a check; totals beyond the softplus threshold
  * and 20 apart at a qubit), writing the values those evaluations produce bit for bit (phi(clip max) = 0,
- * phi(clip min), log(1) = 0).  Results are identical with 0 and 1; 0 evaluates every transcendental like the
+ * phi(clip min), log(1) = 0); and a decode from zero messages and one constant channel LLR (the first decoder of a sandwich) on a
+ * degree-regular graph starts from the closed form of its first iteration (every qubit sends the same value, a check's outputs
+ * differ by the syndrome sign alone: the same float operations, evaluated once per thread).  Results are identical with 0 and 1; 0 evaluates every transcendental like the
  * reference's fixed dataflow (decoding_q.py:732-767) and is what bench.py's headline number uses.
  * FGNN_OPT_FIXED_POINT_EXIT (default 1, effective only with the shortcut on, boxplus-phi, one codeword per workgroup,
  * at most 32 edges per qubit):

@@ -235,6 +235,7 @@ def test_saturation_shortcut_is_exact(name, p):
 
 @pytest.mark.parametrize("name,p,iters,factor", [("ghp882", 0.01, 64, 1.0), ("ghp882", 0.05, 64, 1.0), ("ghp882", 0.09, 64, 1.0),
                                                   ("ghp882", 0.03, 200, 1.0), ("ghp882", 0.03, 3, 1.0), ("ghp882", 0.04, 7, 0.8),
+                                                  ("ghp882", 0.05, 1, 1.0), ("ghp882", 0.05, 2, 0.8), ("ghp1270", 0.05, 1, 0.625),
                                                   ("ghp1270", 0.02, 64, 1.0), ("ghp1270", 0.09, 48, 0.9)])
 def test_fixed_point_exit_is_exact(name, p, iters, factor):
     """FGNN_OPT_FIXED_POINT_EXIT: a workgroup leaves the iteration loop once its messages are provably at a bit-exact fixed
