@@ -139,6 +139,23 @@ __device__ __forceinline__ float logit_row(const float* llr, const int* __restri
     return with_sign(fg_phi(T), neg);
 }
 
+// The same with the exact saturation shortcut: a wave whose rows all see |llr| >= 16.635532 everywhere has phi(|.|) = 0 for every
+// term, T = 0 and phi(T) = phi(clip min) = phi0 — the soft syndrome of a converged codeword.
+__device__ __forceinline__ float logit_row_opt(const float* llr, const int* __restrict__ col, int deg, float phi0, bool shortcut)
+{
+    if (shortcut) {
+        unsigned neg = 0;
+        bool sat = true;
+        for (int j = 0; j < deg; ++j) {
+            const float v = llr[col[j]];
+            neg ^= (v < 0.0f);
+            sat = sat && (FG_ABS(v) >= FG_PHI_MAX);
+        }
+        if (__all(sat)) return with_sign(phi0, neg);
+    }
+    return logit_row(llr, col, deg);
+}
+
 // c->v update of one (DC-regular) check with every message in registers: the phi rule of the benchmark
 // configurations without the LDS round trip of the runtime-degree version.  Same float ops, same order.
 template <int DC>
@@ -493,6 +510,14 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) 
         for (int v = lane; v < n; v += a.tpc) {
             const float* o = a.llr_out + (size_t)b * 3 * n;
             const float X = o[v], Y = o[n + v], Z = o[2 * n + v];  // own writes: visible to this thread
+            // same exact shortcut as in the qubit phase: softplus beyond its threshold, log(1 + exp(-d)) = log 1 = 0 for d >= 20
+            const bool sat = opt_shortcut && FG_ABS(X) > FG_SOFTPLUS_THRESH && FG_ABS(Z) > FG_SOFTPLUS_THRESH &&
+                             FG_ABS((-Z) - (-Y)) >= 20.0f && FG_ABS((-X) - (-Y)) >= 20.0f;
+            if (opt_shortcut && __all(sat)) {
+                llz[v] = softplus_saturated(-X) - (0.0f + FG_MAX(-Z, -Y));
+                llx[v] = softplus_saturated(-Z) - (0.0f + FG_MAX(-X, -Y));
+                continue;
+            }
             llz[v] = fg_softplus(-X) - fg_lse2(-Z, -Y);
             llx[v] = fg_softplus(-Z) - fg_lse2(-X, -Y);
         }
@@ -501,12 +526,12 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) 
         if (a.x_logit)
             for (int r = lane; r < g.rows[0]; r += a.tpc) {
                 const int p0 = g.rptr[0][r];
-                a.x_logit[(size_t)b * g.rows[0] + r] = logit_row(llx, g.rcol[0] + p0, g.rptr[0][r + 1] - p0);
+                a.x_logit[(size_t)b * g.rows[0] + r] = logit_row_opt(llx, g.rcol[0] + p0, g.rptr[0][r + 1] - p0, phi0, opt_shortcut);
             }
         if (a.z_logit)
             for (int r = lane; r < g.rows[1]; r += a.tpc) {
                 const int p0 = g.rptr[1][r];
-                a.z_logit[(size_t)b * g.rows[1] + r] = logit_row(llz, g.rcol[1] + p0, g.rptr[1][r + 1] - p0);
+                a.z_logit[(size_t)b * g.rows[1] + r] = logit_row_opt(llz, g.rcol[1] + p0, g.rptr[1][r + 1] - p0, phi0, opt_shortcut);
             }
     }
 }
