@@ -40,6 +40,7 @@ struct GnnArgs {
     const uint8_t* synd_z;
     float* out;             // [B,3,n]
     const int* index;       // optional: workgroup slot -> sample
+    int nsplit;             // MFMA kernel: a codeword's tiles are dealt to nsplit groups of four waves (small batches: latency)
 };
 
 // vn_msg_mlp_{x,z} on one edge: feature [g, X, Y, Z] -> Dense(40,tanh) -> Dense(20)  (:175-181)
@@ -119,7 +120,8 @@ __global__ void __launch_bounds__(256 * CPB) gnn_mfma_kernel(GraphDev g, Weights
 {
     extern __shared__ float lds[];
     const int cwl = threadIdx.x >> 8, tid = threadIdx.x & 255;
-    const int slot_b = blockIdx.x * CPB + cwl;
+    const int slot = blockIdx.x * CPB + cwl;  // (codeword, part): part p of nsplit takes tiles wave + 4p, wave + 4(p + nsplit), ...
+    const int slot_b = slot / a.nsplit, part = slot - slot_b * a.nsplit;
     const bool active = slot_b < a.B;
     const int b = (active && a.index) ? a.index[slot_b] : slot_b;
     // LDS: the per-lane operand tables [T_COUNT][64] (shared by all waves; one conflict-free ds_read_b32 per
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__(256 * CPB) gnn_mfma_kernel(GraphDev g, Weights
     float* out = a.out + (size_t)b * 3 * n;
     const f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     const int ntiles = (n + 15) >> 4;
-    for (int tile = wave; tile < ntiles; tile += 4) {
+    for (int tile = wave + 4 * part; tile < ntiles; tile += 4 * a.nsplit) {
         const int vraw = tile * 16 + j;
         const bool valid = vraw < n;
         const int v = valid ? vraw : n - 1;
@@ -577,6 +579,7 @@ int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const flo
     a.synd_z = synd_z;
     a.out = out;
     a.index = index;
+    a.nsplit = 1;
     if (w->general) {
         size_t lds_gen = (size_t)a.lds_per_cw * sizeof(float) * (size_t)L.cpb;
         hipLaunchKernelGGL(gnn_general_kernel, dim3(L.blocks), dim3(L.threads), lds_gen, static_cast<hipStream_t>(stream), g->d,
@@ -587,13 +590,18 @@ int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const flo
     if (g->d.dvx == 3 && g->d.dvz == 3 && !g->force_generic) {
         // degree-regular graph: MFMA kernel, four waves per codeword, GNN_CPB codewords per workgroup
         constexpr int GNN_CPB = 4;
+        // few codewords (a compacted feedback round at low p): one codeword's 56 tiles on four waves is 0.33 ms of latency on an
+        // otherwise idle chip; dealt to up to 14 wave-quads it is one tile per wave
+        const int ntiles = (g->d.n + 15) / 16;
+        a.nsplit = 1;
+        while (a.nsplit < 16 && (long long)B * a.nsplit * 2 <= 2048 && a.nsplit * 4 < ntiles) a.nsplit *= 2;
         const size_t lds_mfma = (size_t)(T_COUNT * 64 + GNN_CPB * a.lds_per_cw) * sizeof(float);
         auto kern = gnn_mfma_kernel<3, GNN_CPB>;
         if (lds_mfma > 48 * 1024)
             FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)lds_mfma));
-        hipLaunchKernelGGL(kern, dim3((B + GNN_CPB - 1) / GNN_CPB), dim3(256 * GNN_CPB), lds_mfma, static_cast<hipStream_t>(stream),
-                           g->d, w->d, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(((long long)B * a.nsplit + GNN_CPB - 1) / GNN_CPB)), dim3(256 * GNN_CPB), lds_mfma,
+                           static_cast<hipStream_t>(stream), g->d, w->d, a);
         FGNN_HIP_CHECK(hipGetLastError());
         return FGNN_OK;
     }

@@ -88,7 +88,13 @@ LaunchGeom fgnn_geom(const fgnn_graph* g, int B)
     LaunchGeom L;
     L.tpc = g->tpc;
     L.cpb = g->cpb;
-    L.threads = g->tpc * g->cpb;
+    // fewer codewords than CUs (a compacted feedback round at low p): the launch is pure latency, so a codeword gets a thread per
+    // node instead of one per four — same arithmetic, the kernels index by threads-per-codeword
+    if (!g->user_launch && g->cpb == 1 && B <= 256) {
+        const int nodes = std::max(g->d.n, g->d.m);
+        L.tpc = std::min(1024, std::max(g->tpc, (nodes + 63) / 64 * 64));
+    }
+    L.threads = L.tpc * L.cpb;
     L.blocks = (B + g->cpb - 1) / g->cpb;
     return L;
 }
