@@ -104,11 +104,13 @@ __global__ void __launch_bounds__(1024) syndrome_kernel(GraphDev g, int B, int t
 // errors &= any([hz x_hat ; hx z_hat] != [synd_z ; synd_x])   (feedback_gnn.py:324-330)
 __global__ void __launch_bounds__(1024) flag_kernel(GraphDev g, int B, int tpc, int cpb, const uint8_t* __restrict__ xh,
                                                     const uint8_t* __restrict__ zh, const uint8_t* __restrict__ sx,
-                                                    const uint8_t* __restrict__ sz, uint8_t* __restrict__ errors)
+                                                    const uint8_t* __restrict__ sz, uint8_t* __restrict__ errors,
+                                                    const int* __restrict__ index)
 {
     extern __shared__ uint8_t sm[];
-    const int cwl = threadIdx.x / tpc, lane = threadIdx.x - cwl * tpc, b = blockIdx.x * cpb + cwl;
-    const bool active = b < B;
+    const int cwl = threadIdx.x / tpc, lane = threadIdx.x - cwl * tpc, slot = blockIdx.x * cpb + cwl;
+    const bool active = slot < B;
+    const int b = (active && index) ? index[slot] : slot;  // index: only the listed samples (compacted rounds)
     const int n = g.n;
     unsigned* neq = reinterpret_cast<unsigned*>(sm);  // [cpb]
     uint8_t* lx = sm + ((cpb * sizeof(unsigned) + 15) & ~size_t(15)) + (size_t)cwl * 2 * n;
@@ -135,10 +137,15 @@ __global__ void __launch_bounds__(1024) flag_kernel(GraphDev g, int B, int tpc, 
 // masked overwrite of the estimates (feedback_gnn.py:339-340)
 __global__ void __launch_bounds__(256) merge_kernel(const uint8_t* __restrict__ errors, const uint8_t* __restrict__ xu,
                                                     const uint8_t* __restrict__ zu, long long total, int n,
-                                                    uint8_t* __restrict__ xh, uint8_t* __restrict__ zh)
+                                                    uint8_t* __restrict__ xh, uint8_t* __restrict__ zh,
+                                                    const int* __restrict__ index)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
+    if (index) {  // only the listed samples (compacted rounds): slot -> sample
+        const long long slot = i / n;
+        i = (long long)index[slot] * n + (i - slot * n);
+    }
     if (errors[i / n]) {
         xh[i] = xu[i];
         zh[i] = zu[i];
@@ -260,8 +267,8 @@ extern "C" int fgnn_syndrome(const fgnn_graph* g, const uint8_t* noise_x, const 
     return FGNN_OK;
 }
 
-extern "C" int fgnn_flag_update(const fgnn_graph* g, const uint8_t* x_hat, const uint8_t* z_hat, const uint8_t* synd_x,
-                                const uint8_t* synd_z, int B, uint8_t* errors, void* stream)
+int fgnn_flag_update_impl(const fgnn_graph* g, const uint8_t* x_hat, const uint8_t* z_hat, const uint8_t* synd_x,
+                          const uint8_t* synd_z, int B, uint8_t* errors, const int* index, void* stream)
 {
     if (!g || !x_hat || !z_hat || !synd_x || !synd_z || !errors || B < 0) return fgnn_fail(FGNN_ERR_ARG, "bad flag arguments");
     if (B == 0) return FGNN_OK;
@@ -269,7 +276,25 @@ extern "C" int fgnn_flag_update(const fgnn_graph* g, const uint8_t* x_hat, const
     LaunchGeom L = fgnn_geom(g, B);
     size_t lds = ((L.cpb * sizeof(unsigned) + 15) & ~size_t(15)) + (size_t)L.cpb * 2 * g->d.n;
     hipLaunchKernelGGL(flag_kernel, dim3(L.blocks), dim3(L.threads), lds, static_cast<hipStream_t>(stream), g->d, B, L.tpc, L.cpb,
-                       x_hat, z_hat, synd_x, synd_z, errors);
+                       x_hat, z_hat, synd_x, synd_z, errors, index);
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_flag_update(const fgnn_graph* g, const uint8_t* x_hat, const uint8_t* z_hat, const uint8_t* synd_x,
+                                const uint8_t* synd_z, int B, uint8_t* errors, void* stream)
+{
+    return fgnn_flag_update_impl(g, x_hat, z_hat, synd_x, synd_z, B, errors, nullptr, stream);
+}
+
+int fgnn_merge_impl(const uint8_t* errors, const uint8_t* x_upd, const uint8_t* z_upd, int B, int n, uint8_t* x_hat, uint8_t* z_hat,
+                    const int* index, void* stream)
+{
+    if (!errors || !x_upd || !z_upd || !x_hat || !z_hat || B < 0 || n <= 0) return fgnn_fail(FGNN_ERR_ARG, "bad merge arguments");
+    if (B == 0) return FGNN_OK;
+    const long long total = (long long)B * n;
+    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), errors,
+                       x_upd, z_upd, total, n, x_hat, z_hat, index);
     FGNN_HIP_CHECK(hipGetLastError());
     return FGNN_OK;
 }
@@ -277,13 +302,7 @@ extern "C" int fgnn_flag_update(const fgnn_graph* g, const uint8_t* x_hat, const
 extern "C" int fgnn_merge(const uint8_t* errors, const uint8_t* x_upd, const uint8_t* z_upd, int B, int n, uint8_t* x_hat,
                           uint8_t* z_hat, void* stream)
 {
-    if (!errors || !x_upd || !z_upd || !x_hat || !z_hat || B < 0 || n <= 0) return fgnn_fail(FGNN_ERR_ARG, "bad merge arguments");
-    if (B == 0) return FGNN_OK;
-    const long long total = (long long)B * n;
-    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), errors,
-                       x_upd, z_upd, total, n, x_hat, z_hat);
-    FGNN_HIP_CHECK(hipGetLastError());
-    return FGNN_OK;
+    return fgnn_merge_impl(errors, x_upd, z_upd, B, n, x_hat, z_hat, nullptr, stream);
 }
 
 extern "C" int fgnn_residual_rows(const fgnn_graph* g, int rows_x, int rows_z, const uint8_t* noise_x, const uint8_t* noise_z,

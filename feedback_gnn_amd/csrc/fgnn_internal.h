@@ -108,3 +108,8 @@ int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float n
 int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const float* llr, const float* logit_hx,
                            const float* logit_hz, const uint8_t* synd_x, const uint8_t* synd_z, int B, float* out,
                            const int* index, void* stream);
+// flag update / masked merge restricted to a list of samples (index[0..B), null = samples 0..B-1)
+int fgnn_flag_update_impl(const fgnn_graph* g, const uint8_t* x_hat, const uint8_t* z_hat, const uint8_t* synd_x,
+                          const uint8_t* synd_z, int B, uint8_t* errors, const int* index, void* stream);
+int fgnn_merge_impl(const uint8_t* errors, const uint8_t* x_upd, const uint8_t* z_upd, int B, int n, uint8_t* x_hat, uint8_t* z_hat,
+                    const int* index, void* stream);

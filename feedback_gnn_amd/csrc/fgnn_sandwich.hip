@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) compact_kernel(const uint8_t* __restrict_
 struct Workspace {
     float *llr_a, *llr_b, *xlogit, *zlogit;
     uint8_t *x_upd, *z_upd, *errors;
-    int *index, *count;
+    int *index, *index2, *count;
 };
 
 size_t carve(const fgnn_graph* g, int B, void* base, Workspace* ws)
@@ -75,6 +75,7 @@ size_t carve(const fgnn_graph* g, int B, void* base, Workspace* ws)
     p = take(n * B); if (ws) ws->z_upd = reinterpret_cast<uint8_t*>(p);
     p = take((size_t)B); if (ws) ws->errors = reinterpret_cast<uint8_t*>(p);
     p = take(sizeof(int) * (size_t)B); if (ws) ws->index = reinterpret_cast<int*>(p);
+    p = take(sizeof(int) * (size_t)B); if (ws) ws->index2 = reinterpret_cast<int*>(p);
     p = take(sizeof(int) * 64); if (ws) ws->count = reinterpret_cast<int*>(p);
     return off;
 }
@@ -115,8 +116,11 @@ extern "C" int fgnn_sandwich_decode(const fgnn_graph* g, int num_layers, const i
     const int blk = (B + 255) / 256;
     if (num_layers > 1) hipLaunchKernelGGL(fill_u8, dim3(blk), dim3(256), 0, st, ws.errors, (uint8_t)1, B);  // (:322)
     if (rounds) FGNN_HIP_CHECK(hipMemsetAsync(rounds, 0, (size_t)B, st));
+    int listed = 0;  // compact mode: samples in ws.index from the previous round (the only ones whose estimate changed)
     for (int i = 1; i < num_layers; ++i) {
-        rc = fgnn_flag_update(g, x_hat, z_hat, synd_x, synd_z, B, ws.errors, stream);  // (:324-330)
+        // (:324-330) errors &= flagged(merged estimate): after the first round only the samples of the previous list can change
+        if (compact && i > 1) rc = fgnn_flag_update_impl(g, x_hat, z_hat, synd_x, synd_z, listed, ws.errors, ws.index2, stream);
+        else rc = fgnn_flag_update(g, x_hat, z_hat, synd_x, synd_z, B, ws.errors, stream);
         if (rc) return rc;
         if (rounds) hipLaunchKernelGGL(rounds_add, dim3(blk), dim3(256), 0, st, ws.errors, rounds, B);
         int nact = B;
@@ -142,8 +146,12 @@ extern "C" int fgnn_sandwich_decode(const fgnn_graph* g, int num_layers, const i
                                   ws.llr_a, ws.x_upd, ws.z_upd, last ? nullptr : ws.xlogit, last ? nullptr : ws.zlogit, nullptr,
                                   nullptr, index, stream);  // (:336)
         if (rc) return rc;
-        rc = fgnn_merge(ws.errors, ws.x_upd, ws.z_upd, B, n, x_hat, z_hat, stream);  // (:339-340)
+        rc = fgnn_merge_impl(ws.errors, ws.x_upd, ws.z_upd, nact, n, x_hat, z_hat, index, stream);  // (:339-340)
         if (rc) return rc;
+        if (compact) {  // keep this round's list for the next flag update (the compaction below overwrites ws.index)
+            FGNN_HIP_CHECK(hipMemcpyAsync(ws.index2, ws.index, sizeof(int) * (size_t)nact, hipMemcpyDeviceToDevice, st));
+            listed = nact;
+        }
     }
     if (llr_final)
         FGNN_HIP_CHECK(hipMemcpyAsync(llr_final, ws.llr_a, sizeof(float) * 3 * (size_t)n * B, hipMemcpyDeviceToDevice, st));
