@@ -42,6 +42,8 @@ struct BpArgs {
     int shortcut;             // 1: wave-uniform exact shortcuts for saturated nodes (regular kernel)
     int early_exit;           // 1: leave the iteration loop at a proven fixed point (needs shortcut, cpb == 1, phi rule)
     int sig_off;              // float offset of the fixed-point detector's LDS words (n sign words + 4 flags)
+    uint8_t* flagged;         // optional [B]: 1 iff the decision's syndrome differs from the measured one (feedback_gnn.py:324-328)
+    int flag_off;             // float offset of n decision bytes + one word in LDS (only when flagged != null)
 };
 
 __device__ __forceinline__ unsigned sign_bit(float x) { return fg_f2u(x) >> 31; }
@@ -501,7 +503,27 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) 
             if (Y < best) { best = Y; d = 3; }
             a.x_hat[(size_t)b * n + v] = (uint8_t)(d & 1);
             a.z_hat[(size_t)b * n + v] = (uint8_t)(d >> 1);
+            if (a.flagged) reinterpret_cast<uint8_t*>(msg + a.flag_off)[v] = (uint8_t)d;
         }
+    if (a.flagged) {
+        // Fused flag test of the sandwich (feedback_gnn.py:324-328): does the estimate reproduce the measured syndrome?  hx rows
+        // check z_hat (bit 1 of the decision), hz rows x_hat (bit 0); the decisions of this codeword sit in LDS.
+        uint8_t* dec = reinterpret_cast<uint8_t*>(msg + a.flag_off);
+        unsigned* fword = reinterpret_cast<unsigned*>(dec + ((n + 3) & ~3));
+        if (lane == 0) *fword = 0u;
+        __syncthreads();
+        unsigned mine = 0;
+        if (active)
+            for (int c = lane; c < g.m; c += a.tpc) {
+                const int sh = c < g.m_x ? 1 : 0;
+                unsigned par = (c < g.m_x ? sx[c] : sz[c - g.m_x]) & 1u;
+                for (int e = g.cptr[c]; e < g.cptr[c + 1]; ++e) par ^= (dec[g.cvn[e]] >> sh) & 1u;
+                mine |= par;
+            }
+        if (mine) atomicOr(fword, 1u);
+        __syncthreads();
+        if (active && lane == 0) a.flagged[b] = (uint8_t)(*fword != 0u);
+    }
     if (!a.x_logit && !a.z_logit) return;
     __syncthreads();  // every thread is done reading messages
     float* llx = msg;      // [n] llr_x of cal_logit
@@ -564,7 +586,7 @@ int launch_bp4(const fgnn_graph* g, const BpArgs& a, const LaunchGeom& L, size_t
 int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float normalization_factor, const float* llr_ch,
                          float llr_const, const uint8_t* synd_x, const uint8_t* synd_z, int B, const float* msg_init_x,
                          const float* msg_init_z, float* llr_out, uint8_t* x_hat, uint8_t* z_hat, float* x_logit,
-                         float* z_logit, float* msg_out_x, float* msg_out_z, const int* index, void* stream)
+                         float* z_logit, float* msg_out_x, float* msg_out_z, const int* index, uint8_t* flagged, void* stream)
 {
     if (!g) return fgnn_fail(FGNN_ERR_ARG, "graph is NULL");
     if (B < 0 || num_iter < 0) return fgnn_fail(FGNN_ERR_ARG, "B and num_iter must be >= 0");
@@ -613,6 +635,13 @@ int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float n
         if (with_det <= 160 * 1024) lds_bytes = with_det;
         else a.early_exit = 0;
     }
+    a.flagged = flagged;
+    a.flag_off = 0;
+    if (flagged) {  // n decision bytes + one word per codeword, behind everything else
+        if (L.cpb != 1) return fgnn_fail(FGNN_ERR_STATE, "the fused flag test needs one codeword per workgroup");
+        a.flag_off = (int)(lds_bytes / sizeof(float));
+        lds_bytes += (size_t)((g->d.n + 3) & ~3) + sizeof(unsigned);
+    }
     if (lds_bytes > 160 * 1024) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident kernel");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool prof = g->prof_on && (size_t)(2 * g->prof_n + 1) < g->prof_ev.size();
@@ -639,5 +668,5 @@ extern "C" int fgnn_bp4_decode(const fgnn_graph* g, int cn_type, int num_iter, f
                                void* stream)
 {
     return fgnn_bp4_decode_impl(g, cn_type, num_iter, normalization_factor, llr_ch, llr_const, synd_x, synd_z, B, msg_init_x,
-                                msg_init_z, llr_out, x_hat, z_hat, x_logit, z_logit, msg_out_x, msg_out_z, nullptr, stream);
+                                msg_init_z, llr_out, x_hat, z_hat, x_logit, z_logit, msg_out_x, msg_out_z, nullptr, nullptr, stream);
 }

@@ -100,11 +100,12 @@ struct LaunchGeom {
 };
 LaunchGeom fgnn_geom(const fgnn_graph* g, int B);
 
-// internal entry points with an optional slot->sample indirection (compacted sandwich rounds)
+// internal entry points with an optional slot->sample indirection (compacted sandwich rounds); bp4: flagged[b] (optional) = the
+// decision's syndrome differs from the measured one — the sandwich's flag test fused into the decoder's epilogue
 int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float normalization_factor, const float* llr_ch,
                          float llr_const, const uint8_t* synd_x, const uint8_t* synd_z, int B, const float* msg_init_x,
                          const float* msg_init_z, float* llr_out, uint8_t* x_hat, uint8_t* z_hat, float* x_logit,
-                         float* z_logit, float* msg_out_x, float* msg_out_z, const int* index, void* stream);
+                         float* z_logit, float* msg_out_x, float* msg_out_z, const int* index, uint8_t* flagged, void* stream);
 int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const float* llr, const float* logit_hx,
                            const float* logit_hz, const uint8_t* synd_x, const uint8_t* synd_z, int B, float* out,
                            const int* index, void* stream);

@@ -20,6 +20,13 @@ __global__ void __launch_bounds__(256) fill_u8(uint8_t* p, uint8_t v, int count)
     if (i < count) p[i] = v;
 }
 
+// errors[b] &= flagged[b]: the flag test of the next round (feedback_gnn.py:324-330), computed by the decoder's epilogue
+__global__ void __launch_bounds__(256) and_u8(uint8_t* __restrict__ errors, const uint8_t* __restrict__ flagged, int B)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) errors[i] = (uint8_t)((errors[i] != 0) && (flagged[i] != 0));
+}
+
 __global__ void __launch_bounds__(256) rounds_add(const uint8_t* __restrict__ errors, uint8_t* __restrict__ rounds, int B)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -53,7 +60,7 @@ __global__ void __launch_bounds__(256) compact_kernel(const uint8_t* __restrict_
 
 struct Workspace {
     float *llr_a, *llr_b, *xlogit, *zlogit;
-    uint8_t *x_upd, *z_upd, *errors;
+    uint8_t *x_upd, *z_upd, *errors, *fnext;
     int *index, *index2, *count;
 };
 
@@ -74,6 +81,7 @@ size_t carve(const fgnn_graph* g, int B, void* base, Workspace* ws)
     p = take(n * B); if (ws) ws->x_upd = reinterpret_cast<uint8_t*>(p);
     p = take(n * B); if (ws) ws->z_upd = reinterpret_cast<uint8_t*>(p);
     p = take((size_t)B); if (ws) ws->errors = reinterpret_cast<uint8_t*>(p);
+    p = take((size_t)B); if (ws) ws->fnext = reinterpret_cast<uint8_t*>(p);
     p = take(sizeof(int) * (size_t)B); if (ws) ws->index = reinterpret_cast<int*>(p);
     p = take(sizeof(int) * (size_t)B); if (ws) ws->index2 = reinterpret_cast<int*>(p);
     p = take(sizeof(int) * 64); if (ws) ws->count = reinterpret_cast<int*>(p);
@@ -109,19 +117,24 @@ extern "C" int fgnn_sandwich_decode(const fgnn_graph* g, int num_layers, const i
     int rc;
     // decoders[0] on the constant channel LLR (feedback_gnn.py:311-313,321)
     const bool only = num_layers == 1;  // no feedback round: nobody reads the soft syndromes
+    // One codeword per workgroup (every code of >= 256 nodes): the decoders' epilogues compute the flag test of the next round
+    // (does the estimate reproduce the syndrome?), so no separate pass re-reads x_hat / z_hat.  errors_1 = all-true & flagged (:322-330).
+    const bool fuse = g->cpb == 1;
     rc = fgnn_bp4_decode_impl(g, cn_types[0], iters[0], factors[0], nullptr, llr_const, synd_x, synd_z, B, nullptr, nullptr,
                               ws.llr_a, x_hat, z_hat, only ? nullptr : ws.xlogit, only ? nullptr : ws.zlogit, nullptr, nullptr,
-                              nullptr, stream);
+                              nullptr, (fuse && !only) ? ws.errors : nullptr, stream);
     if (rc) return rc;
     const int blk = (B + 255) / 256;
-    if (num_layers > 1) hipLaunchKernelGGL(fill_u8, dim3(blk), dim3(256), 0, st, ws.errors, (uint8_t)1, B);  // (:322)
+    if (num_layers > 1 && !fuse) hipLaunchKernelGGL(fill_u8, dim3(blk), dim3(256), 0, st, ws.errors, (uint8_t)1, B);  // (:322)
     if (rounds) FGNN_HIP_CHECK(hipMemsetAsync(rounds, 0, (size_t)B, st));
     int listed = 0;  // compact mode: samples in ws.index from the previous round (the only ones whose estimate changed)
     for (int i = 1; i < num_layers; ++i) {
         // (:324-330) errors &= flagged(merged estimate): after the first round only the samples of the previous list can change
-        if (compact && i > 1) rc = fgnn_flag_update_impl(g, x_hat, z_hat, synd_x, synd_z, listed, ws.errors, ws.index2, stream);
-        else rc = fgnn_flag_update(g, x_hat, z_hat, synd_x, synd_z, B, ws.errors, stream);
-        if (rc) return rc;
+        if (!fuse) {
+            if (compact && i > 1) rc = fgnn_flag_update_impl(g, x_hat, z_hat, synd_x, synd_z, listed, ws.errors, ws.index2, stream);
+            else rc = fgnn_flag_update(g, x_hat, z_hat, synd_x, synd_z, B, ws.errors, stream);
+            if (rc) return rc;
+        }
         if (rounds) hipLaunchKernelGGL(rounds_add, dim3(blk), dim3(256), 0, st, ws.errors, rounds, B);
         int nact = B;
         const int* index = nullptr;
@@ -144,10 +157,13 @@ extern "C" int fgnn_sandwich_decode(const fgnn_graph* g, int num_layers, const i
         const bool last = i == num_layers - 1;
         rc = fgnn_bp4_decode_impl(g, cn_types[i], iters[i], factors[i], ws.llr_b, 0.0f, synd_x, synd_z, nact, nullptr, nullptr,
                                   ws.llr_a, ws.x_upd, ws.z_upd, last ? nullptr : ws.xlogit, last ? nullptr : ws.zlogit, nullptr,
-                                  nullptr, index, stream);  // (:336)
+                                  nullptr, index, (fuse && !last) ? ws.fnext : nullptr, stream);  // (:336)
         if (rc) return rc;
         rc = fgnn_merge_impl(ws.errors, ws.x_upd, ws.z_upd, nact, n, x_hat, z_hat, index, stream);  // (:339-340)
         if (rc) return rc;
+        // next round's flag test: the merged estimate of a sample still in `errors` IS this round's x_upd/z_upd, whose syndrome test
+        // the decoder just wrote; samples outside `errors` stay outside (their fnext entry is stale or unset, and 0 & x = 0)
+        if (fuse && !last) hipLaunchKernelGGL(and_u8, dim3(blk), dim3(256), 0, st, ws.errors, ws.fnext, B);
         if (compact) {  // keep this round's list for the next flag update (the compaction below overwrites ws.index)
             FGNN_HIP_CHECK(hipMemcpyAsync(ws.index2, ws.index, sizeof(int) * (size_t)nact, hipMemcpyDeviceToDevice, st));
             listed = nact;
