@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256 * CPB) gnn_mfma_kernel(GraphDev g, Weights
                 for (int i = 0; i < 5; ++i) esum[i] = (k == 0) ? msg[i] : esum[i] + msg[i];
             }
 #pragma unroll
-            for (int i = 0; i < 5; ++i) mean[s2][i] = esum[i] / (float)DV;  // reduce_mean (:139-141)
+            for (int i = 0; i < 5; ++i) mean[s2][i] = DV == 3 ? fg_div3(esum[i]) : esum[i] / (float)DV;  // reduce_mean (:139-141)
         }
         // vn_embed_mlp on [m_x | m_z | X,Y,Z] then _llr_inv_embed  (:186)
         FRESH_TAB();

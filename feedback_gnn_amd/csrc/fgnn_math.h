@@ -170,7 +170,39 @@ FG_FN float fg_phi_gnn(float x)
     return fg_log(y + 1.0f) - fg_log(y - 1.0f);
 }
 
+/* x / 3 (the mean over a qubit's three edges, feedback_gnn.py:139-141) for any finite x: the CPU divides, the device multiplies by
+ * RN(1/3) and corrects with one exact remainder — the correctly rounded quotient for all 2^32 - 2^24 finite inputs
+ * (tests/div_exhaustive.hip). */
+FG_FN float fg_div3(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float c = 0.333333343f; /* 0x3eaaaaab */
+    const float q = x * c;
+    const float y = FG_FMA(FG_FMA(-3.0f, q, x), c, q);
+    return (x == 0.0f) ? x : y; /* -0 / 3 = -0: the remainder step would return +0 */
+#else
+    return x / 3.0f;
+#endif
+}
+
 /* ---- tanh / atanh (feedback-GNN activations, 'boxplus' check-node rule) ------------------ */
+/* a / b for b = a + 2, a in [0, 2^58] (the quotient of fg_tanh).  The CPU divides.  The device refines v_rcp_f32 with exact
+ * remainders; the result is the correctly rounded quotient — the CPU's — for every float in that range, which
+ * tests/div_exhaustive.hip checks one by one on the GPU (tests/test_math.py).  About half the slots of the general division
+ * sequence (no v_div_scale / v_div_fixup: nothing here needs rescaling). */
+FG_FN float fg_div_em1(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf(b);
+    float q = a * r;
+    float e = FG_FMA(-b, q, a);
+    q = FG_FMA(e, r, q);
+    return q;
+#else
+    return a / b;
+#endif
+}
+
 FG_FN float fg_tanh(float x)
 {
     /* tanh|x| = em1/(em1+2), em1 = expm1(2|x|) = 2^k*(e^r - 1) + (2^k - 1) with the reduction and the
@@ -189,7 +221,7 @@ FG_FN float fg_tanh(float x)
     float pm1 = FG_FMA(r * r, q, r);                         /* e^r - 1 */
     float sc = fg_u2f((fg_f2u(tt) << 23) + 0x3f800000u);     /* 2^k, k in [0, 58] */
     float em1 = FG_FMA(sc, pm1, sc - 1.0f);
-    float y = em1 / (em1 + 2.0f);
+    float y = fg_div_em1(em1, em1 + 2.0f);
     return fg_u2f(fg_f2u(y) | (fg_f2u(x) & 0x80000000u));
 }
 

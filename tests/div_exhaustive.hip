@@ -1,0 +1,76 @@
+// tests/div_exhaustive.hip — exhaustive proof obligations of fg_div_em1 and fg_div3 (feedback_gnn_amd/csrc/fgnn_math.h) on the target GPU.
+//
+// fg_tanh needs em1 / (em1 + 2) for em1 in [0, e^40].  On the device that quotient is formed from v_rcp_f32 and fma refinement steps
+// (about half the instruction slots of the compiler's general IEEE division); on the CPU (the oracle) it is a plain division.  The
+// two are the same function iff the device sequence returns the correctly rounded quotient for EVERY float in that range — which
+// this program checks, all ~1.57e9 of them, against the compiler's IEEE division on the same device.
+//   build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tests/div_exhaustive.hip -o tests/_build/div_exhaustive
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#include "../feedback_gnn_amd/csrc/fgnn_math.h"
+
+__global__ void __launch_bounds__(256) check(uint32_t first, uint32_t last, unsigned long long* bad, uint32_t* first_bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long mine = 0;
+    for (uint64_t u = (uint64_t)first + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; u <= last; u += stride) {
+        const float a = fg_u2f((uint32_t)u);
+        const float b = a + 2.0f;
+        const float fast = fg_div_em1(a, b);
+        const float ieee = a / b;
+        if (fg_f2u(fast) != fg_f2u(ieee)) {
+            ++mine;
+            atomicMin(first_bad, (uint32_t)u);
+        }
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+__global__ void __launch_bounds__(256) check3(unsigned long long* bad, uint32_t* first_bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long mine = 0;
+    for (uint64_t u = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; u < (1ull << 32); u += stride) {
+        if (((uint32_t)u & 0x7f800000u) == 0x7f800000u) continue;  // inf / nan never reach the mean
+        const float x = fg_u2f((uint32_t)u);
+        if (fg_f2u(fg_div3(x)) != fg_f2u(x / 3.0f)) {
+            ++mine;
+            atomicMin(first_bad, (uint32_t)u);
+        }
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+int main()
+{
+    const uint32_t last = 0x5c800000u;  // 2^58 > e^40 = 2.35e17: every em1 fg_tanh can produce (its argument is clamped to 40)
+    unsigned long long* d_bad;
+    uint32_t* d_first;
+    unsigned long long bad = 0;
+    uint32_t first_bad = 0xffffffffu;
+    if (hipMalloc(&d_bad, 8) != hipSuccess || hipMalloc(&d_first, 4) != hipSuccess) return 2;
+    (void)hipMemcpy(d_bad, &bad, 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_first, &first_bad, 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(check, dim3(256 * 32), dim3(256), 0, 0, 0u, last, d_bad, d_first);
+    if (hipDeviceSynchronize() != hipSuccess) return 2;
+    (void)hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&first_bad, d_first, 4, hipMemcpyDeviceToHost);
+    std::printf("fg_div_em1 vs IEEE division on %llu inputs: %llu mismatches", (unsigned long long)last + 1ull, bad);
+    if (bad) std::printf(" (first at bits 0x%08x)", first_bad);
+    std::printf("\n");
+    unsigned long long bad3 = 0;
+    first_bad = 0xffffffffu;
+    (void)hipMemcpy(d_bad, &bad3, 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_first, &first_bad, 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(check3, dim3(256 * 32), dim3(256), 0, 0, d_bad, d_first);
+    if (hipDeviceSynchronize() != hipSuccess) return 2;
+    (void)hipMemcpy(&bad3, d_bad, 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&first_bad, d_first, 4, hipMemcpyDeviceToHost);
+    std::printf("fg_div3 vs IEEE division on all finite floats: %llu mismatches", bad3);
+    if (bad3) std::printf(" (first at bits 0x%08x)", first_bad);
+    std::printf("\n");
+    return (bad || bad3) ? 1 : 0;
+}

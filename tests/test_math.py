@@ -1,5 +1,6 @@
 """The shared float32 elementary functions (fgnn_math.h) and the Philox stream, probed through the oracle."""
 import numpy as np
+import pytest
 
 from oracle import oracle as O
 
@@ -55,3 +56,16 @@ def test_philox_known_answers():
              [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
     for ctr, key, out in kats:
         assert list(O.philox(ctr, key)) == out
+
+
+@pytest.mark.gpu
+def test_device_division_sequences_equal_ieee_division_exhaustively():
+    """fg_tanh's quotient em1/(em1+2) and the mean's x/3 are plain divisions on the CPU and short rcp/fma sequences on the device
+    (fgnn_math.h: fg_div_em1, fg_div3).  tests/div_exhaustive.hip runs both against the compiler's IEEE division on the GPU for
+    every float of their domains (1.55e9 and 4.28e9 inputs): zero mismatches is what makes the two builds one function."""
+    import subprocess
+    import __graft_entry__ as entry
+    res = subprocess.run([entry.build_div_exhaustive()], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout
+    assert "fg_div_em1 vs IEEE division on 1551892481 inputs: 0 mismatches" in res.stdout
+    assert "fg_div3 vs IEEE division on all finite floats: 0 mismatches" in res.stdout
