@@ -120,7 +120,7 @@ __device__ __forceinline__ void cn_update(float* msg, const int* __restrict__ sl
         const float clipv = 0.99999988f;
         for (int j = 0; j < deg; ++j) {
             int s = slot[j];
-            float q = (1.0f / msg[s]) * P;
+            float q = fg_rcp_unit(msg[s]) * P;
             q = (FG_ABS(q) < 1e-7f) ? 0.0f : q;
             q = FG_MIN(FG_MAX(q, -clipv), clipv);
             msg[s] = (2.0f * fg_atanh(q)) * factor;

@@ -225,11 +225,39 @@ FG_FN float fg_tanh(float x)
     return fg_u2f(fg_f2u(y) | (fg_f2u(x) & 0x80000000u));
 }
 
+/* 2a / (1 - a) for a in [0, 1 - 2^-23] (the quotient of fg_atanh) and 1 / t for 2^-126 <= |t| <= 1 (the 'boxplus' rule divides the
+ * product of tanh values by each factor, decoding_q.py:340-345): device = v_rcp_f32 + exact-remainder fma steps, CPU = division;
+ * equal for every input of those ranges (tests/div_exhaustive.hip).  Outside its range fg_rcp_unit falls back to the division. */
+FG_FN float fg_div_atanh(float a)
+{
+    const float num = a + a, den = 1.0f - a;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf(den);
+    float q = num * r;
+    q = FG_FMA(FG_FMA(-den, q, num), r, q);
+    return q;
+#else
+    return num / den;
+#endif
+}
+FG_FN float fg_rcp_unit(float t)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float at = FG_ABS(t);
+    if (at >= 1.17549435e-38f && at <= 1.0f) {
+        float r = __builtin_amdgcn_rcpf(t);
+        r = FG_FMA(FG_FMA(-t, r, 1.0f), r, r);
+        return r;
+    }
+#endif
+    return 1.0f / t;
+}
+
 /* atanh(x) = 0.5*log1p(2|x|/(1-|x|)), |x| <= 1-2^-23 */
 FG_FN float fg_atanh(float x)
 {
     float ax = FG_ABS(x);
-    float r = 0.5f * fg_log1p((ax + ax) / (1.0f - ax));
+    float r = 0.5f * fg_log1p(fg_div_atanh(ax));
     return fg_u2f(fg_f2u(r) | (fg_f2u(x) & 0x80000000u));
 }
 

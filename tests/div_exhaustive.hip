@@ -44,6 +44,52 @@ __global__ void __launch_bounds__(256) check3(unsigned long long* bad, uint32_t*
     if (mine) atomicAdd(bad, mine);
 }
 
+__global__ void __launch_bounds__(256) check_atanh(unsigned long long* bad, uint32_t* first_bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long mine = 0;
+    for (uint64_t u = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; u <= 0x3f7ffffeu; u += stride) {  // a in [0, 1 - 2^-23]
+        const float a = fg_u2f((uint32_t)u);
+        if (fg_f2u(fg_div_atanh(a)) != fg_f2u((a + a) / (1.0f - a))) {
+            ++mine;
+            atomicMin(first_bad, (uint32_t)u);
+        }
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+__global__ void __launch_bounds__(256) check_rcp(unsigned long long* bad, uint32_t* first_bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long mine = 0;
+    for (uint64_t u = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; u < (1ull << 32); u += stride) {
+        if (((uint32_t)u & 0x7f800000u) == 0x7f800000u) continue;
+        const float t = fg_u2f((uint32_t)u);
+        if (fg_f2u(fg_rcp_unit(t)) != fg_f2u(1.0f / t)) {
+            ++mine;
+            atomicMin(first_bad, (uint32_t)u);
+        }
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+template <typename K>
+static int run_check(K kernel, const char* what, unsigned long long* d_bad, uint32_t* d_first)
+{
+    unsigned long long bad = 0;
+    uint32_t first_bad = 0xffffffffu;
+    (void)hipMemcpy(d_bad, &bad, 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_first, &first_bad, 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(kernel, dim3(256 * 32), dim3(256), 0, 0, d_bad, d_first);
+    if (hipDeviceSynchronize() != hipSuccess) return 2;
+    (void)hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&first_bad, d_first, 4, hipMemcpyDeviceToHost);
+    std::printf("%s: %llu mismatches", what, bad);
+    if (bad) std::printf(" (first at bits 0x%08x)", first_bad);
+    std::printf("\n");
+    return bad ? 1 : 0;
+}
+
 int main()
 {
     const uint32_t last = 0x5c800000u;  // 2^58 > e^40 = 2.35e17: every em1 fg_tanh can produce (its argument is clamped to 40)
@@ -72,5 +118,8 @@ int main()
     std::printf("fg_div3 vs IEEE division on all finite floats: %llu mismatches", bad3);
     if (bad3) std::printf(" (first at bits 0x%08x)", first_bad);
     std::printf("\n");
-    return (bad || bad3) ? 1 : 0;
+    int rc = (bad || bad3) ? 1 : 0;
+    rc |= run_check(check_atanh, "fg_div_atanh vs IEEE division on every a in [0, 1 - 2^-23]", d_bad, d_first);
+    rc |= run_check(check_rcp, "fg_rcp_unit vs IEEE division on all finite floats", d_bad, d_first);
+    return rc;
 }

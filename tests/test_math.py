@@ -69,3 +69,5 @@ def test_device_division_sequences_equal_ieee_division_exhaustively():
     assert res.returncode == 0, res.stdout
     assert "fg_div_em1 vs IEEE division on 1551892481 inputs: 0 mismatches" in res.stdout
     assert "fg_div3 vs IEEE division on all finite floats: 0 mismatches" in res.stdout
+    assert "fg_div_atanh vs IEEE division on every a in [0, 1 - 2^-23]: 0 mismatches" in res.stdout
+    assert "fg_rcp_unit vs IEEE division on all finite floats: 0 mismatches" in res.stdout
