@@ -208,6 +208,43 @@ def test_gnn_mfma_and_valu_kernels_agree():
         assert np.array_equal(ref, a), f"MFMA kernel: max|d|={np.abs(ref - a).max()} first {np.argwhere(ref != a)[:4]}"
 
 
+@pytest.mark.parametrize("name,wfile", [("ghp882", WEIGHTS_882), ("ghp1270", WEIGHTS_1270)])
+def test_small_launch_geometry_is_exact(name, wfile):
+    """Launches of at most 256 codewords get a thread per node (fgnn_geom) and, below 1 024 codewords, the feedback GNN deals a
+    codeword's tiles to several wave-quads (nsplit): a compacted feedback round on a handful of samples.  Every kernel on the path
+    must give the same bits for the first samples of a small launch and of a large one (and both equal the oracle)."""
+    from feedback_gnn_amd.graph import GnnWeights
+    from feedback_gnn_amd.weights_io import read_weight_list
+    gg, og = gpu_graph(name), oracle_graph(name)
+    L0 = llr_const(0.05)
+    w = read_weight_list(wfile)
+    gw = GnnWeights(w, gg.device)
+    Bbig = 1500
+    (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, 0.10, Bbig, first=31337)
+    big = gg.bp4_decode(tx, tz, 20, "boxplus-phi", 1.0, llr_const=L0, return_msgs=True)
+    big_gnn = gg.feedback_gnn(gw, big["llr"], big["z_logit"], big["x_logit"], tx, tz)
+    big2 = gg.bp4_decode(tx, tz, 7, "boxplus-phi", 0.9, llr_ch=big_gnn)
+    for B in (1, 3, 64, 200, 256, 257):
+        small = gg.bp4_decode(tx[:B].contiguous(), tz[:B].contiguous(), 20, "boxplus-phi", 1.0, llr_const=L0, return_msgs=True)
+        for k in ("llr", "x_hat", "z_hat", "x_logit", "z_logit", "msg_x", "msg_z"):
+            assert torch.equal(small[k], big[k][:B]), (B, k)
+        sg = gg.feedback_gnn(gw, small["llr"], small["z_logit"], small["x_logit"], tx[:B].contiguous(), tz[:B].contiguous())
+        assert torch.equal(sg, big_gnn[:B]), (B, "gnn")
+        s2 = gg.bp4_decode(tx[:B].contiguous(), tz[:B].contiguous(), 7, "boxplus-phi", 0.9, llr_ch=sg)
+        for k in ("llr", "x_hat", "z_hat"):
+            assert torch.equal(s2[k], big2[k][:B]), (B, k, "stage 2")
+        sx_s, sz_s = gg.syndrome(gx[:B].contiguous(), gz[:B].contiguous())
+        assert torch.equal(sx_s, tx[:B]) and torch.equal(sz_s, tz[:B])
+        r_s = gg.residual(gx[:B].contiguous(), gz[:B].contiguous(), small["x_hat"], small["z_hat"])
+        r_b = gg.residual(gx, gz, big["x_hat"], big["z_hat"])
+        for a_, b_ in zip(r_s, r_b):
+            assert torch.equal(a_, b_[:B]), (B, "residual")
+    o = og.bp4_decode(sx[:64], sz[:64], 20, "boxplus-phi", 1.0, llr_const=L0, return_msgs=True)
+    _assert_bp_equal(o, {k: v[:64] for k, v in big.items()}, "large launch vs oracle")
+    ref = og.feedback_gnn(w, o["llr"], o["z_logit"], o["x_logit"], sx[:64], sz[:64])
+    assert np.array_equal(ref, big_gnn[:64].cpu().numpy())
+
+
 @pytest.mark.parametrize("name,p", [("ghp882", 0.01), ("ghp882", 0.06), ("ghp1270", 0.02)])
 def test_saturation_shortcut_is_exact(name, p):
     """Low p: codewords converge early and the wave-uniform shortcut fires for most of the 64 iterations.
