@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — decoded codewords/s of the BP4 + feedback-GNN sandwich on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts N ranks itself, one per GPU, before touching a GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one Monte-Carlo batch of `--batch` (default 65 536) codewords per GPU through the whole hot
@@ -42,7 +42,15 @@ def algorithmic_bytes_per_codeword(n, m, E, iters):
     return per_iter * iters + epilogue
 
 
-def main():
+GNN_PEAK_TFLOPS = 157.3  # same guide: f32 MFMA (= f32 vector) peak
+
+
+def gnn_flops_per_codeword(n, E):
+    """E*2*(4*40+40*20) + n*2*(43*40+40*3) = 13.4 MFLOP ([[882,24]]) / 19.3 MFLOP ([[1270,28]])."""
+    return E * 2 * (4 * 40 + 40 * 20) + n * 2 * (43 * 40 + 40 * 3)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -54,20 +62,89 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="codewords for the CPU baseline (0 = skip, -1 = sized from a probe to ~15 s of CPU work)")
     ap.add_argument("--no-extras", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-build", action="store_true",
+                    help="do not run make: only check that the libraries exist (profiled runs, child ranks)")
+    return ap.parse_args(argv)
 
-    import numpy as np
+
+def build_once(no_build):
+    """Compile (or, with --no-build, just locate) the native libraries BEFORE this process makes any GPU call: make and hipcc
+    run as children of a process that has not initialised the GPU.  Ranks started by a launcher serialise on a file lock;
+    all but the first find everything up to date."""
+    import fcntl
+    import __graft_entry__ as entry
+    from feedback_gnn_amd import _lib
+    if no_build:
+        if not os.path.exists(_lib.LIB_PATH):
+            raise SystemExit(f"--no-build: {_lib.LIB_PATH} is missing")
+        return
+    with open(os.path.join(ROOT, ".bench_build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            entry.build()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start N ranks (one process per GPU, the way the reference
+    pins one process per GPU id, /root/reference n882.py:9,15-21) and relay rank 0's JSON line.  This parent never touches a
+    GPU: torch.cuda.device_count() does not initialise one, and the children are fresh interpreters."""
+    import socket
+    import subprocess
     import torch
+    backend = os.environ.get("FGNN_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible "
+                         "(FGNN_BENCH_BACKEND=gloo lets ranks share a device for a self-test)")
+    if not args.no_build:  # in a child interpreter: this parent loads no GPU library at all
+        rc = subprocess.call([sys.executable, "-c", "import __graft_entry__ as e; e.build()"], cwd=ROOT)
+        if rc != 0:
+            raise SystemExit("bench.py: build failed")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    child_argv = [a for a in argv if a != "--no-build"] + ["--no-build"]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + child_argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    build_once(args.no_build)  # before the first GPU call of this process
+
+    import numpy as np
+    import torch
+
     # one process per GPU; FGNN_BENCH_BACKEND=gloo (self-test of the multi-process flow on a 1-GPU box) lets several
     # ranks share a device and reduces through host memory
     backend = os.environ.get("FGNN_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or (backend == "nccl" and local_rank >= ndev):
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, {ndev} visible")
+    dev_index = local_rank % ndev if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
@@ -85,12 +162,6 @@ def main():
         c = t.cpu()
         dist.all_reduce(c, op=op)
         return c.to(t.device)
-
-    import __graft_entry__ as entry
-    if rank == 0:
-        entry.build()
-    if dist is not None:
-        dist.barrier()
 
     import feedback_gnn_amd as F
     from feedback_gnn_amd._lib import lib
@@ -130,7 +201,7 @@ def main():
     for _ in range(W):
         model.mc_step(B, args.p, counts)
     counts.zero_()
-    g.profile_enable(K * len(iters))
+    g.profile_enable(K * (2 * len(iters) - 1))  # BP4 launches + feedback-GNN launches of the timed region
     sync()
     t0 = time.perf_counter()
     for _ in range(K):
@@ -151,22 +222,32 @@ def main():
     if rank == 0:
         n, m, E = g.n, g.m_x + g.m_z, g.E_x + g.E_z
         dom = [ms for ms, it, b in launches if it == iters[0] and b == B]
-        dom_ms = float(np.mean(dom)) if dom else float("nan")
+        dom_ms = float(np.mean(dom)) if dom else None
         alg_bytes = algorithmic_bytes_per_codeword(n, m, E, iters[0]) * B
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
+        gnn = [ms for ms, it, b in launches if it == -1 and b == B]
+        gnn_ms = float(np.mean(gnn)) if gnn else None
+        gnn_flops = gnn_flops_per_codeword(n, E) * B
+        gnn_tf = gnn_flops / (gnn_ms * 1e-3) / 1e12 if gnn_ms else None
+        # HBM bytes / VALU instruction counts are NOT measured by this run: they come from the rocprofv3 PMC passes that
+        # tools/final_profile.sh collects with the same shapes and summarises into profiles/traffic.json
         traffic = None
         valu = None
+        tsrc = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = f"bp4_{args.code}_it{iters[0]}_B{B}"
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-                vi = tj.get(key, {}).get("valu_wave_insts_per_launch")
-                if vi:
+                ent = tj.get(f"bp4_{args.code}_it{iters[0]}_B{B}", {})
+                traffic = ent.get("hbm_bytes_per_launch")
+                vi = ent.get("valu_wave_insts_per_launch")
+                if traffic is not None or vi:
+                    tsrc = f"profiles/traffic.json (offline rocprofv3 --pmc passes, {ent.get('taken_at', 'round 1 build')}); not measured in this run"
+                if vi and dom_ms:
                     # the kernel's true limiter: VALU issue.  1024 SIMDs, 2 cycles per wave64 instruction, 2.4 GHz peak clock
                     # (the chip holds ~2.34 GHz on this kernel, so this understates the utilisation slightly)
-                    valu = {"wave_insts_per_launch": vi, "issue_utilisation_at_2.4GHz": vi * 2 / (1024 * dom_ms * 1e-3 * 2.4e9)}
+                    valu = {"wave_insts_per_launch": vi, "issue_utilisation_at_2.4GHz": vi * 2 / (1024 * dom_ms * 1e-3 * 2.4e9),
+                            "source": tsrc}
             except Exception:
                 traffic = None
         info = g.info()
@@ -182,13 +263,18 @@ def main():
                        "code": code.name, "batch_per_gpu": B, "global_batch": world * B, "bp_iters": iters, "p": args.p,
                        "parallelism": f"batch-sharded x{world}, no data-path collective",
                        "threads_per_codeword": info["threads_per_codeword"], "seed": SEED},
-            "roofline": {"bound": "hbm", "kernel": f"bp4_kernel<boxplus-phi>, {iters[0]} iterations, B={B}",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_launch_ms": dom_ms, "launches_timed": len(dom),
+            "roofline": {"bound": "valu-issue (hbm figure is the SURVEY §8d streaming model: `achieved` is an effective bandwidth)",
+                         "kernel": f"bp4_kernel<boxplus-phi>, {iters[0]} iterations, B={B}",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                         "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": dom_ms, "launches_timed": len(dom),
                          "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
+                         "gnn": {"bound": "mfma", "kernel": f"feedback-GNN kernel, B={B}", "achieved": gnn_tf,
+                                 "peak": GNN_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gnn_tf / GNN_PEAK_TFLOPS if gnn_tf else None,
+                                 "avg_launch_ms": gnn_ms, "launches_timed": len(gnn), "algorithmic_flops_per_launch": gnn_flops},
                          "note": "messages stay in LDS for all iterations: `achieved` is the reference's streaming-model "
                                  "bytes / kernel time (effective bandwidth); the kernel itself is VALU-issue bound "
-                                 "(DESIGN.md §4), `traffic` = HBM bytes actually moved per launch (rocprofv3 PMC)"},
+                                 "(DESIGN.md §4), `traffic` = HBM bytes actually moved per launch (rocprofv3 PMC, offline)"},
             "counts": {"flagged": int(cnt[0]), "block_errors": int(cnt[1]), "samples": int(cnt[2])},
         }
 

@@ -382,7 +382,7 @@ extern "C" int fgnn_bp4_backward(const fgnn_graph* g, int num_iter, float normal
     if (!g->d.rptr[0] || !g->d.rptr[1] || !g->d.tptr[0] || !g->d.tptr[1])
         return fgnn_fail(FGNN_ERR_STATE, "logit row sets not installed (fgnn_graph_set_rows)");
     if (B == 0) return FGNN_OK;
-    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    FGNN_DEVICE_GUARD(g->device);
     const GraphDev& d = g->d;
     BwArgs a;
     a.B = B;
@@ -429,7 +429,7 @@ extern "C" int fgnn_feedback_gnn_backward(const fgnn_graph* g, const fgnn_weight
         return fgnn_fail(FGNN_ERR_ARG, "the reverse pass exists for the num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, "
                                        "mean, tanh, use_bias configuration only");
     if (B == 0) return FGNN_OK;
-    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    FGNN_DEVICE_GUARD(g->device);
     GnnBwArgs a;
     a.B = B;
     a.llr = llr;

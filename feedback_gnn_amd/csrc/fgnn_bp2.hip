@@ -177,7 +177,7 @@ extern "C" int fgnn_bp2_decode(const fgnn_graph* g, int cn_type, int num_iter, f
     if (cn_type < 0 || cn_type > 2) return fgnn_fail(FGNN_ERR_ARG, "Unknown node type.");
     if (!soft_out && !hard_out) return fgnn_fail(FGNN_ERR_ARG, "no output buffer");
     if (B == 0) return FGNN_OK;
-    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    FGNN_DEVICE_GUARD(g->device);
     LaunchGeom L = fgnn_geom(g, B);
     Bp2Args a;
     a.B = B;

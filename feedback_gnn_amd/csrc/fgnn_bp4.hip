@@ -595,7 +595,7 @@ int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float n
     if ((x_logit && !g->d.rptr[0]) || (z_logit && !g->d.rptr[1]))
         return fgnn_fail(FGNN_ERR_STATE, "logit row sets not installed (fgnn_graph_set_rows)");
     if (B == 0) return FGNN_OK;
-    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    FGNN_DEVICE_GUARD(g->device);
     LaunchGeom L = fgnn_geom(g, B);
     BpArgs a;
     a.B = B;
@@ -644,20 +644,14 @@ int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float n
     }
     if (lds_bytes > 160 * 1024) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident kernel");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool prof = g->prof_on && (size_t)(2 * g->prof_n + 1) < g->prof_ev.size();
-    if (prof) FGNN_HIP_CHECK(hipEventRecord(g->prof_ev[2 * g->prof_n], st));
+    fgnn_prof_scope prof(g, st);
     int rc;
     switch (cn_type) {
     case FGNN_CN_BOXPLUS_PHI: rc = launch_bp4<FGNN_CN_BOXPLUS_PHI>(g, a, L, lds_bytes, st); break;
     case FGNN_CN_MINSUM: rc = launch_bp4<FGNN_CN_MINSUM>(g, a, L, lds_bytes, st); break;
     default: rc = launch_bp4<FGNN_CN_BOXPLUS>(g, a, L, lds_bytes, st); break;
     }
-    if (prof && rc == FGNN_OK) {
-        FGNN_HIP_CHECK(hipEventRecord(g->prof_ev[2 * g->prof_n + 1], st));
-        g->prof_iters[g->prof_n] = num_iter;
-        g->prof_batch[g->prof_n] = B;
-        g->prof_n++;
-    }
+    if (rc == FGNN_OK) prof.done(num_iter, B);
     return rc;
 }
 

@@ -258,7 +258,7 @@ extern "C" int fgnn_syndrome(const fgnn_graph* g, const uint8_t* noise_x, const 
 {
     if (!g || !noise_x || !noise_z || !synd_x || !synd_z || B < 0) return fgnn_fail(FGNN_ERR_ARG, "bad syndrome arguments");
     if (B == 0) return FGNN_OK;
-    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    FGNN_DEVICE_GUARD(g->device);
     LaunchGeom L = fgnn_geom(g, B);
     size_t lds = (size_t)L.cpb * 2 * g->d.n;
     hipLaunchKernelGGL(syndrome_kernel, dim3(L.blocks), dim3(L.threads), lds, static_cast<hipStream_t>(stream), g->d, B, L.tpc,
@@ -272,7 +272,7 @@ int fgnn_flag_update_impl(const fgnn_graph* g, const uint8_t* x_hat, const uint8
 {
     if (!g || !x_hat || !z_hat || !synd_x || !synd_z || !errors || B < 0) return fgnn_fail(FGNN_ERR_ARG, "bad flag arguments");
     if (B == 0) return FGNN_OK;
-    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    FGNN_DEVICE_GUARD(g->device);
     LaunchGeom L = fgnn_geom(g, B);
     size_t lds = ((L.cpb * sizeof(unsigned) + 15) & ~size_t(15)) + (size_t)L.cpb * 2 * g->d.n;
     hipLaunchKernelGGL(flag_kernel, dim3(L.blocks), dim3(L.threads), lds, static_cast<hipStream_t>(stream), g->d, B, L.tpc, L.cpb,
@@ -313,7 +313,7 @@ extern "C" int fgnn_residual_rows(const fgnn_graph* g, int rows_x, int rows_z, c
     if (rows_x < 0 || rows_x > 5 || rows_z < 0 || rows_z > 5 || !g->d.rptr[rows_x] || !g->d.rptr[rows_z])
         return fgnn_fail(FGNN_ERR_STATE, "row sets for the residual check not installed (fgnn_graph_set_rows)");
     if (B == 0) return FGNN_OK;
-    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    FGNN_DEVICE_GUARD(g->device);
     LaunchGeom L = fgnn_geom(g, B);
     size_t lds = ((L.cpb * sizeof(unsigned) + 15) & ~size_t(15)) + (size_t)L.cpb * 2 * g->d.n;
     hipLaunchKernelGGL(residual_kernel, dim3(L.blocks), dim3(L.threads), lds, static_cast<hipStream_t>(stream), g->d, rows_x, rows_z, B,

@@ -379,7 +379,7 @@ extern "C" int fgnn_weights_create(const float* const host_arrays[12], int devic
     if (!host_arrays || !out) return fgnn_fail(FGNN_ERR_ARG, "NULL argument");
     for (int i = 0; i < 12; ++i)
         if (!host_arrays[i]) return fgnn_fail(FGNN_ERR_ARG, "weight array is NULL");
-    FGNN_HIP_CHECK(hipSetDevice(device));
+    FGNN_DEVICE_GUARD(device);
     // blob layout (floats): w1t_x 160 | b1_x 40 | w2_x 800 | b2_x 20 | same for z | wet 1760 | be 40 | wout 160 | bout 4
     std::vector<float> h;
     size_t off[12];
@@ -490,7 +490,7 @@ extern "C" int fgnn_weights_create_general(const fgnn_gnn_config* cfg, const flo
     if (num_arrays != 3 * L * (1 + bias)) return fgnn_fail(FGNN_ERR_ARG, "wrong number of weight arrays for this configuration");
     for (int i = 0; i < num_arrays; ++i)
         if (!host_arrays[i]) return fgnn_fail(FGNN_ERR_ARG, "weight array is NULL");
-    FGNN_HIP_CHECK(hipSetDevice(device));
+    FGNN_DEVICE_GUARD(device);
     fgnn_weights* w = new fgnn_weights();
     w->device = device;
     w->blob = nullptr;
@@ -551,7 +551,7 @@ extern "C" int fgnn_weights_create_general(const fgnn_gnn_config* cfg, const flo
 extern "C" void fgnn_weights_destroy(fgnn_weights* w)
 {
     if (!w) return;
-    (void)hipSetDevice(w->device);
+    fgnn_device_guard _dg(w->device);
     if (w->blob) (void)hipFree(w->blob);
     delete w;
 }
@@ -565,7 +565,7 @@ int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const flo
     if (B < 0) return fgnn_fail(FGNN_ERR_ARG, "B must be >= 0");
     if (w->device != g->device) return fgnn_fail(FGNN_ERR_ARG, "weights and graph live on different devices");
     if (B == 0) return FGNN_OK;
-    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    FGNN_DEVICE_GUARD(g->device);
     LaunchGeom L = fgnn_geom(g, B);
     GnnArgs a;
     a.B = B;
@@ -580,11 +580,13 @@ int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const flo
     a.out = out;
     a.index = index;
     a.nsplit = 1;
+    fgnn_prof_scope prof(g, static_cast<hipStream_t>(stream));
     if (w->general) {
         size_t lds_gen = (size_t)a.lds_per_cw * sizeof(float) * (size_t)L.cpb;
         hipLaunchKernelGGL(gnn_general_kernel, dim3(L.blocks), dim3(L.threads), lds_gen, static_cast<hipStream_t>(stream), g->d,
                            w->gen, a);
         FGNN_HIP_CHECK(hipGetLastError());
+        prof.done(FGNN_PROF_TAG_GNN, B);
         return FGNN_OK;
     }
     if (g->d.dvx == 3 && g->d.dvz == 3 && !g->force_generic) {
@@ -603,11 +605,13 @@ int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const flo
         hipLaunchKernelGGL(kern, dim3((unsigned)(((long long)B * a.nsplit + GNN_CPB - 1) / GNN_CPB)), dim3(256 * GNN_CPB), lds_mfma,
                            static_cast<hipStream_t>(stream), g->d, w->d, a);
         FGNN_HIP_CHECK(hipGetLastError());
+        prof.done(FGNN_PROF_TAG_GNN, B);
         return FGNN_OK;
     }
     size_t lds_bytes = (size_t)a.lds_per_cw * sizeof(float) * (size_t)L.cpb;
     hipLaunchKernelGGL(gnn_kernel, dim3(L.blocks), dim3(L.threads), lds_bytes, static_cast<hipStream_t>(stream), g->d, w->d, a);
     FGNN_HIP_CHECK(hipGetLastError());
+    prof.done(FGNN_PROF_TAG_GNN, B);
     return FGNN_OK;
 }
 

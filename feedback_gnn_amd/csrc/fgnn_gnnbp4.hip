@@ -439,7 +439,7 @@ extern "C" int fgnn_gnnbp4_weights_create(const float* const host_arrays[30], in
         return fgnn_fail(FGNN_ERR_ARG, "the GNN_BP4 kernel is built for num_embed_dims=20, num_hidden_units=40");
     for (int i = 0; i < 30; ++i)
         if (!host_arrays[i]) return fgnn_fail(FGNN_ERR_ARG, "weight array is NULL");
-    FGNN_HIP_CHECK(hipSetDevice(device));
+    FGNN_DEVICE_GUARD(device);
     std::vector<float> h;
     auto push = [&](size_t count) {
         size_t o = h.size();
@@ -551,7 +551,7 @@ extern "C" int fgnn_gnnbp4_weights_create(const float* const host_arrays[30], in
 extern "C" void fgnn_gnnbp4_weights_destroy(fgnn_gnnbp4_weights* w)
 {
     if (!w) return;
-    (void)hipSetDevice(w->device);
+    fgnn_device_guard _dg(w->device);
     if (w->blob) (void)hipFree(w->blob);
     delete w;
 }
@@ -573,7 +573,7 @@ extern "C" int fgnn_gnnbp4_decode(const fgnn_graph* g, const fgnn_gnnbp4_weights
     if (w->device != g->device) return fgnn_fail(FGNN_ERR_ARG, "weights and graph live on different devices");
     if (B == 0) return FGNN_OK;
     if (!workspace || ws_bytes < fgnn_gnnbp4_workspace_bytes(g, B)) return fgnn_fail(FGNN_ERR_ARG, "workspace too small");
-    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    FGNN_DEVICE_GUARD(g->device);
     Args a;
     a.B = B;
     a.num_iter = num_iter;

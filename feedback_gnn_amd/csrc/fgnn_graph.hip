@@ -113,7 +113,7 @@ extern "C" int fgnn_graph_create(int n, int m_x, int m_z, int nnz_x, const int32
         for (int i = 0; i < nnz[s]; ++i)
             if (chk[s][i] < 0 || chk[s][i] >= m[s] || var[s][i] < 0 || var[s][i] >= n)
                 return fgnn_fail(FGNN_ERR_ARG, "edge index out of range");
-    FGNN_HIP_CHECK(hipSetDevice(device));
+    FGNN_DEVICE_GUARD(device);
     fgnn_graph* g = new fgnn_graph();
     std::memset(&g->d, 0, sizeof(g->d));
     std::memset(g->row_alloc, 0, sizeof(g->row_alloc));
@@ -194,7 +194,7 @@ extern "C" int fgnn_graph_create(int n, int m_x, int m_z, int nnz_x, const int32
 extern "C" void fgnn_graph_destroy(fgnn_graph* g)
 {
     if (!g) return;
-    (void)hipSetDevice(g->device);
+    fgnn_device_guard _dg(g->device);
     for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
     for (void* p : g->basis_dev)
         if (p) (void)hipFree(p);
@@ -211,7 +211,7 @@ extern "C" int fgnn_graph_set_rows(fgnn_graph* g, int which, int rows, int nnz, 
     for (int i = 0; i < nnz; ++i)
         if (row[i] < 0 || row[i] >= rows || col[i] < 0 || col[i] >= g->d.n)
             return fgnn_fail(FGNN_ERR_ARG, "row-set index out of range");
-    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    FGNN_DEVICE_GUARD(g->device);
     std::vector<int> ptr, c;
     coo_to_csr(rows, nnz, row, col, ptr, c);
     for (void*& p : g->row_alloc[which])
@@ -319,7 +319,7 @@ extern "C" int fgnn_graph_edges(const fgnn_graph* g, int side, int32_t* chk, int
 extern "C" int fgnn_profile_enable(fgnn_graph* g, int max_launches)
 {
     if (!g || max_launches < 0) return fgnn_fail(FGNN_ERR_ARG, "bad profile arguments");
-    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    FGNN_DEVICE_GUARD(g->device);
     for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
     g->prof_ev.clear();
     g->prof_n = 0;
@@ -339,7 +339,7 @@ extern "C" int fgnn_profile_enable(fgnn_graph* g, int max_launches)
 extern "C" int fgnn_profile_read(fgnn_graph* g, float* ms, int32_t* iters, int32_t* batch, int cap, int32_t* count)
 {
     if (!g || !ms || !iters || !batch || !count) return fgnn_fail(FGNN_ERR_ARG, "NULL argument");
-    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    FGNN_DEVICE_GUARD(g->device);
     int n = g->prof_n < cap ? g->prof_n : cap;
     if (g->prof_n > 0) FGNN_HIP_CHECK(hipEventSynchronize(g->prof_ev[2 * g->prof_n - 1]));
     for (int i = 0; i < n; ++i) {

@@ -94,6 +94,50 @@ int fgnn_fail(int code, const std::string& s);
             return fgnn_fail(FGNN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));        \
     } while (0)
 
+// Every ABI entry point runs on its handle's device and leaves the caller's current device as it found it.
+struct fgnn_device_guard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit fgnn_device_guard(int device)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+        else prev = -1;  // nothing to restore
+    }
+    ~fgnn_device_guard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    fgnn_device_guard(const fgnn_device_guard&) = delete;
+    fgnn_device_guard& operator=(const fgnn_device_guard&) = delete;
+};
+#define FGNN_DEVICE_GUARD(device)                                                                     \
+    fgnn_device_guard _dev_guard(device);                                                             \
+    if (_dev_guard.err != hipSuccess)                                                                 \
+        return fgnn_fail(FGNN_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_dev_guard.err))
+
+// Optional per-launch timing (fgnn_profile_*): HIP events on the launch stream around one kernel launch.  `tag` is what
+// fgnn_profile_read reports as `iters`: the BP4 iteration count, or FGNN_PROF_TAG_GNN for a feedback-GNN launch.
+constexpr int FGNN_PROF_TAG_GNN = -1;
+struct fgnn_prof_scope {
+    const fgnn_graph* g;
+    hipStream_t st;
+    bool on;
+    fgnn_prof_scope(const fgnn_graph* g_, hipStream_t st_) : g(g_), st(st_)
+    {
+        on = g->prof_on && (size_t)(2 * g->prof_n + 1) < g->prof_ev.size();
+        if (on && hipEventRecord(g->prof_ev[2 * g->prof_n], st) != hipSuccess) on = false;
+    }
+    void done(int tag, int B)
+    {
+        if (!on) return;
+        if (hipEventRecord(g->prof_ev[2 * g->prof_n + 1], st) != hipSuccess) return;
+        g->prof_iters[g->prof_n] = tag;
+        g->prof_batch[g->prof_n] = B;
+        g->prof_n++;
+    }
+};
+
 // launch geometry shared by the per-codeword kernels
 struct LaunchGeom {
     int tpc, cpb, threads, blocks;

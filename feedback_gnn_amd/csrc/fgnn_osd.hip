@@ -157,7 +157,7 @@ extern "C" int fgnn_graph_set_basis(fgnn_graph* g, int side, int rank, const int
     const int ms = side ? g->d.m_z : g->d.m_x;
     for (int r = 0; r < rank; ++r)
         if (pivot_rows[r] < 0 || pivot_rows[r] >= ms) return fgnn_fail(FGNN_ERR_ARG, "pivot row out of range");
-    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    FGNN_DEVICE_GUARD(g->device);
     if (g->basis_dev[side]) (void)hipFree(g->basis_dev[side]);
     g->basis_dev[side] = nullptr;
     FGNN_HIP_CHECK(hipMalloc(&g->basis_dev[side], sizeof(int) * (size_t)rank));
@@ -174,7 +174,7 @@ extern "C" int fgnn_osd0(const fgnn_graph* g, int side, const float* marg, const
     if ((!marg && !llr_bin) || !synd || !e_hat || B < 0) return fgnn_fail(FGNN_ERR_ARG, "required buffer is NULL");
     const int count = index ? nact : B;
     if (count <= 0) return FGNN_OK;
-    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    FGNN_DEVICE_GUARD(g->device);
     OsdArgs a;
     a.side = side;
     a.rank = g->basis_rank[side];

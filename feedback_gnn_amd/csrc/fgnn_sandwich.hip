@@ -109,7 +109,7 @@ extern "C" int fgnn_sandwich_decode(const fgnn_graph* g, int num_layers, const i
         return fgnn_fail(FGNN_ERR_STATE, "sandwich needs stage_one logit rows (pcm_x_perp=hz, pcm_z_perp=hx)");
     if (B == 0) return FGNN_OK;
     if (ws_bytes < carve(g, B, nullptr, nullptr) || !workspace) return fgnn_fail(FGNN_ERR_ARG, "workspace too small");
-    FGNN_HIP_CHECK(hipSetDevice(g->device));
+    FGNN_DEVICE_GUARD(g->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     Workspace ws;
     carve(g, B, workspace, &ws);

@@ -85,10 +85,11 @@ int fgnn_graph_info(const fgnn_graph* g, int32_t info[16]);
 /* canonical (qubit, check)-sorted edge lists, host output: chk[E_s], var[E_s] for side 0 (hx) / 1 (hz) */
 int fgnn_graph_edges(const fgnn_graph* g, int side, int32_t* chk, int32_t* var);
 
-/* Per-launch timing of the BP4 kernel (no reference equivalent; sim_ber only has wall-clock per point,
- * misc.py:639,696): HIP events are recorded on the launch stream right before and after every BP4 launch,
+/* Per-launch timing of the BP4 and feedback-GNN kernels (no reference equivalent; sim_ber only has wall-clock per point,
+ * misc.py:639,696): HIP events are recorded on the launch stream right before and after every BP4 / feedback-GNN launch,
  * standalone or inside fgnn_sandwich_decode, up to max_launches (0 disables).  fgnn_profile_read waits for the
- * last one and returns ms / num_iter / B per launch in host arrays of length cap. */
+ * last one and returns ms / tag / B per launch in host arrays of length cap; tag = num_iter of a BP4 launch,
+ * -1 for a feedback-GNN launch. */
 int fgnn_profile_enable(fgnn_graph* g, int max_launches);
 int fgnn_profile_read(fgnn_graph* g, float* ms, int32_t* iters, int32_t* batch, int cap, int32_t* count);
 

@@ -11,7 +11,7 @@ tail -2 $O/pytest_gpu.log
 python bench.py > $O/bench.json 2> $O/bench.err
 cat $O/bench.json
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-extras > $O/trace_bench.json 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-extras --no-build > $O/trace_bench.json 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_WAIT_INST_LDS"; do
   tag=$(echo $set | cut -d' ' -f1)
   timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $O/pmc_$tag -- python3 tools/prof_kernels.py ghp882 65536 fixed > $O/pmc_$tag.log 2>&1
