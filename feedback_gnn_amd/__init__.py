@@ -21,7 +21,8 @@ def __getattr__(name):
                 "Second_Stage_GNN_BP_Model"):
         from . import feedback_gnn as _f
         return getattr(_f, name)
-    if name in ("sim_ber", "count_block_errors", "PlotBER"):
+    if name in ("sim_ber", "count_block_errors", "PlotBER", "allreduce_counts", "shard_range", "pack_decisions",
+                "unpack_decisions", "gather_packed", "gather_decisions"):
         from . import utils as _u
         return getattr(_u, name)
     if name in ("LDPCBPDecoder", "BP_BSC_Model"):

@@ -227,7 +227,67 @@ __global__ void __launch_bounds__(256) count_kernel(const uint8_t* __restrict__ 
     }
 }
 
+// Bit-packed decisions for the all-gather of SURVEY §8(e): row b = the 2n bits [x_hat[b,:] | z_hat[b,:]], most significant bit
+// first inside a byte (numpy.packbits order), ceil(2n/8) bytes per codeword.  One thread per output byte; the 8 input bytes of
+// a thread are contiguous except across the x|z seam, a wave reads 512 consecutive input bytes and writes 64 consecutive bytes.
+__global__ void __launch_bounds__(256) pack_kernel(const uint8_t* __restrict__ x_hat, const uint8_t* __restrict__ z_hat,
+                                                   long long total, int n, int nb, uint8_t* __restrict__ packed)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long b = i / nb;
+    const int byte = (int)(i - b * nb);
+    const uint8_t* xr = x_hat + b * n;
+    const uint8_t* zr = z_hat + b * n;
+    unsigned v = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int pos = byte * 8 + k;
+        unsigned bit = 0;
+        if (pos < n) bit = xr[pos] & 1u;
+        else if (pos < 2 * n) bit = zr[pos - n] & 1u;
+        v |= bit << (7 - k);
+    }
+    packed[i] = (uint8_t)v;
+}
+
+__global__ void __launch_bounds__(256) unpack_kernel(const uint8_t* __restrict__ packed, long long total, int n, int nb,
+                                                     uint8_t* __restrict__ x_hat, uint8_t* __restrict__ z_hat)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over B * 2n decisions
+    if (i >= total) return;
+    const long long b = i / (2 * n);
+    const int pos = (int)(i - b * 2 * n);
+    const uint8_t v = (uint8_t)((packed[b * nb + (pos >> 3)] >> (7 - (pos & 7))) & 1u);
+    if (pos < n) x_hat[b * n + pos] = v;
+    else z_hat[b * n + pos - n] = v;
+}
+
 }  // namespace
+
+extern "C" int fgnn_pack_decisions(const uint8_t* x_hat, const uint8_t* z_hat, int B, int n, uint8_t* packed, void* stream)
+{
+    if (!x_hat || !z_hat || !packed || B < 0 || n <= 0) return fgnn_fail(FGNN_ERR_ARG, "bad pack arguments");
+    if (B == 0) return FGNN_OK;
+    const int nb = (2 * n + 7) / 8;
+    const long long total = (long long)B * nb;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x_hat,
+                       z_hat, total, n, nb, packed);
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_unpack_decisions(const uint8_t* packed, int B, int n, uint8_t* x_hat, uint8_t* z_hat, void* stream)
+{
+    if (!x_hat || !z_hat || !packed || B < 0 || n <= 0) return fgnn_fail(FGNN_ERR_ARG, "bad unpack arguments");
+    if (B == 0) return FGNN_OK;
+    const int nb = (2 * n + 7) / 8;
+    const long long total = (long long)B * 2 * n;
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), packed,
+                       total, n, nb, x_hat, z_hat);
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}
 
 extern "C" int fgnn_pauli_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, uint8_t* noise_x,
                                 uint8_t* noise_z, void* stream)

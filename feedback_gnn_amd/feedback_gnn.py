@@ -157,7 +157,8 @@ class Sandwich_BP_GNN_Evaluation_Model:
     "flagged" iff its s_hat row is non-zero and a block error iff its ls_hat row is non-zero.
 
     MI355X-native extras (keyword-only): ``seed``; ``compact`` (run the feedback rounds only on samples
-    still flagged — identical outputs); ``rank``/``world_size`` shard the global sample stream;
+    still flagged — identical decisions, hence identical ``s_hat`` / ``ls_hat`` / counters; the intermediate marginals of a
+    sample that left the flagged set are those of the last decoder that ran on it, see `TannerGraph.sandwich_decode`); ``rank``/``world_size`` shard the global sample stream;
     ``model.mc_step(batch_size, p, counts)`` accumulates (#flagged, #block errors, #samples) into a
     device int64[3] without any host synchronisation.
     """
@@ -233,8 +234,18 @@ class Sandwich_BP_GNN_Evaluation_Model:
         err = (flags & 1).bool()
         return o["noise_x"][err], o["noise_z"][err]
 
-    def mc_step(self, batch_size, p, counts):
-        """One Monte-Carlo batch with on-device counting (sim_ber's qldpc branch, misc.py:647-669)."""
+    def rewind(self, batches, batch_size):
+        """Give back the last ``batches`` batches of ``batch_size`` samples per rank of the global sample stream (sim_ber's
+        deferred read-back discards batches issued beyond the one a point ends with)."""
+        self._next_sample -= int(batches) * self.world_size * int(batch_size)
+        if self._next_sample < 0:
+            raise ValueError("rewind beyond the start of the sample stream")
+
+    def mc_step(self, batch_size, p, counts=None):
+        """One Monte-Carlo batch with on-device counting (sim_ber's qldpc branch, misc.py:647-669): ``counts`` (device int64[3],
+        created zeroed when None) += (#flagged, #block errors, #samples).  No host synchronisation."""
+        if counts is None:
+            counts = torch.zeros(3, dtype=torch.int64, device=self.graph.device)
         o = self.decode(batch_size, p)
         _, _, flags = self.graph.residual(o["noise_x"], o["noise_z"], o["x_hat"], o["z_hat"], want_arrays=False)
         return self.graph.count_flags(flags, counts)

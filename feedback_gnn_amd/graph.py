@@ -31,6 +31,14 @@ def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _resolve_device(device):
+    """torch.device with an explicit index: None and a bare "cuda" mean torch's CURRENT device (not device 0)."""
+    device = torch.device("cuda" if device is None else device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 REDUCE_OPS = {"sum": 0, "mean": 1, "max": 2, "min": 3}
 ACTIVATIONS = {None: 0, "linear": 0, "tanh": 1, "relu": 2, "sigmoid": 3}
 SHIPPED_GNN_CONFIG = (20, 40, 2, "mean", "tanh", True)
@@ -68,15 +76,15 @@ class GnnWeights:
             raise ValueError(f"feedback-GNN weights must have shapes {shapes}, got {[a.shape for a in arrays]}")
         self.arrays = arrays
         self.config = (int(D), int(H), int(L), red, act, bool(bias))
-        self.device = torch.device(device)
+        self.device = _resolve_device(device)
         self.general = force_general or self.config != SHIPPED_GNN_CONFIG
         ptrs = (C.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
         h = C.c_void_p()
         if self.general:
             cfg = (C.c_int * 6)(int(D), int(H), int(L), REDUCE_OPS[red], ACTIVATIONS[act], int(bool(bias)))
-            check(_lib.lib().fgnn_weights_create_general(cfg, ptrs, len(arrays), self.device.index or 0, C.byref(h)))
+            check(_lib.lib().fgnn_weights_create_general(cfg, ptrs, len(arrays), self.device.index, C.byref(h)))
         else:
-            check(_lib.lib().fgnn_weights_create(ptrs, self.device.index or 0, C.byref(h)))
+            check(_lib.lib().fgnn_weights_create(ptrs, self.device.index, C.byref(h)))
         self.handle = h
 
     def __del__(self):
@@ -95,11 +103,11 @@ class TannerGraph:
     """
 
     def __init__(self, code, stage_one=True, device=None):
-        if device is None:
-            device = torch.device("cuda", torch.cuda.current_device())
-        self.device = torch.device(device)
-        if self.device.type != "cuda":
+        if device is not None and torch.device(device).type != "cuda":
             raise _lib.FgnnError("the BP4/feedback-GNN decoder runs on a HIP device only (no CPU fallback)")
+        if not torch.cuda.is_available():
+            raise _lib.FgnnError("no HIP device: the BP4/feedback-GNN decoder has no CPU fallback")
+        self.device = _resolve_device(device)
         L = _lib.lib()
         self.code = code
         hx, hz = np.asarray(code.hx), np.asarray(code.hz)
@@ -110,7 +118,7 @@ class TannerGraph:
         self.E_x, self.E_z = len(rx), len(rz)
         h = C.c_void_p()
         check(L.fgnn_graph_create(self.n, self.m_x, self.m_z, self.E_x, _np_ptr(rx), _np_ptr(cx), self.E_z, _np_ptr(rz),
-                                  _np_ptr(cz), self.device.index or 0, C.byref(h)))
+                                  _np_ptr(cz), self.device.index, C.byref(h)))
         self.handle = h
         self.stage_one = bool(stage_one)
         xp, zp = (hz, hx) if stage_one else (np.asarray(code.hx_perp), np.asarray(code.hz_perp))
@@ -183,6 +191,14 @@ class TannerGraph:
         if tuple(t.shape) != tuple(shape):
             raise ValueError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
         return t.contiguous()
+
+    def _chk_out(self, t, shape, dtype, name):
+        """A buffer the library writes in place: validated like an input, but a non-contiguous view is an error (a silent copy
+        would receive the result instead of the caller's tensor)."""
+        self._chk(t, shape, dtype, name)
+        if not t.is_contiguous():
+            raise ValueError(f"{name} is written in place and must be contiguous")
+        return t
 
     def _new(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
@@ -298,14 +314,17 @@ class TannerGraph:
     def pauli_noise(self, seed, p, first_sample, B):
         ex = self._new((B, self.n), torch.uint8)
         ez = self._new((B, self.n), torch.uint8)
-        check(_lib.lib().fgnn_pauli_noise(int(seed), float(np.float32(p)), int(first_sample), B, self.n, _ptr(ex), _ptr(ez),
-                                          _stream(self.device)))
+        with torch.cuda.device(self.device):  # graph-less entry points run on the current device
+            check(_lib.lib().fgnn_pauli_noise(int(seed), float(np.float32(p)), int(first_sample), B, self.n, _ptr(ex), _ptr(ez),
+                                              _stream(self.device)))
         return ex, ez
 
     def pauli_noise_wt(self, seed, wt, first_sample, B):
         ex = self._new((B, self.n), torch.uint8)
         ez = self._new((B, self.n), torch.uint8)
-        check(_lib.lib().fgnn_pauli_noise_wt(int(seed), int(wt), int(first_sample), B, self.n, _ptr(ex), _ptr(ez), _stream(self.device)))
+        with torch.cuda.device(self.device):
+            check(_lib.lib().fgnn_pauli_noise_wt(int(seed), int(wt), int(first_sample), B, self.n, _ptr(ex), _ptr(ez),
+                                                 _stream(self.device)))
         return ex, ez
 
     def syndrome(self, ex, ez):
@@ -319,24 +338,32 @@ class TannerGraph:
 
     def flag_update(self, x_hat, z_hat, synd_x, synd_z, errors):
         B = int(x_hat.shape[0])
-        check(_lib.lib().fgnn_flag_update(self.handle, _ptr(self._chk(x_hat, (B, self.n), torch.uint8, "x_hat")),
-                                          _ptr(self._chk(z_hat, (B, self.n), torch.uint8, "z_hat")),
-                                          _ptr(self._chk(synd_x, (B, self.m_x), torch.uint8, "synd_x")),
-                                          _ptr(self._chk(synd_z, (B, self.m_z), torch.uint8, "synd_z")), B,
-                                          _ptr(self._chk(errors, (B,), torch.uint8, "errors")), _stream(self.device)))
+        x_hat = self._chk(x_hat, (B, self.n), torch.uint8, "x_hat")
+        z_hat = self._chk(z_hat, (B, self.n), torch.uint8, "z_hat")
+        synd_x = self._chk(synd_x, (B, self.m_x), torch.uint8, "synd_x")
+        synd_z = self._chk(synd_z, (B, self.m_z), torch.uint8, "synd_z")
+        errors = self._chk_out(errors, (B,), torch.uint8, "errors")
+        check(_lib.lib().fgnn_flag_update(self.handle, _ptr(x_hat), _ptr(z_hat), _ptr(synd_x), _ptr(synd_z), B, _ptr(errors),
+                                          _stream(self.device)))
         return errors
 
     def merge(self, errors, x_upd, z_upd, x_hat, z_hat):
         B = int(x_hat.shape[0])
-        for t, nm in ((x_upd, "x_upd"), (z_upd, "z_upd"), (x_hat, "x_hat"), (z_hat, "z_hat")):
-            self._chk(t, (B, self.n), torch.uint8, nm)
-        check(_lib.lib().fgnn_merge(_ptr(errors), _ptr(x_upd), _ptr(z_upd), B, self.n, _ptr(x_hat), _ptr(z_hat),
-                                    _stream(self.device)))
+        errors = self._chk(errors, (B,), torch.uint8, "errors")
+        x_upd = self._chk(x_upd, (B, self.n), torch.uint8, "x_upd")
+        z_upd = self._chk(z_upd, (B, self.n), torch.uint8, "z_upd")
+        x_hat = self._chk_out(x_hat, (B, self.n), torch.uint8, "x_hat")
+        z_hat = self._chk_out(z_hat, (B, self.n), torch.uint8, "z_hat")
+        with torch.cuda.device(self.device):  # fgnn_merge takes no graph: it runs on the current device
+            check(_lib.lib().fgnn_merge(_ptr(errors), _ptr(x_upd), _ptr(z_upd), B, self.n, _ptr(x_hat), _ptr(z_hat),
+                                        _stream(self.device)))
 
     def residual(self, ex, ez, x_hat, z_hat, want_arrays=True):
         B = int(ex.shape[0])
-        for t, nm in ((ex, "noise_x"), (ez, "noise_z"), (x_hat, "x_hat"), (z_hat, "z_hat")):
-            self._chk(t, (B, self.n), torch.uint8, nm)
+        ex = self._chk(ex, (B, self.n), torch.uint8, "noise_x")
+        ez = self._chk(ez, (B, self.n), torch.uint8, "noise_z")
+        x_hat = self._chk(x_hat, (B, self.n), torch.uint8, "x_hat")
+        z_hat = self._chk(z_hat, (B, self.n), torch.uint8, "z_hat")
         s_hat = self._new((B, self.m_z + self.m_x), torch.uint8) if want_arrays else None
         ls_hat = self._new((B, self.rows_hxp + self.rows_hzp), torch.uint8) if want_arrays else None
         flags = self._new((B,), torch.uint8)
@@ -346,7 +373,12 @@ class TannerGraph:
 
     def count_flags(self, flags, counts):
         """counts (uint64/int64 [3] on device) += (#flagged, #block errors, #samples)."""
-        check(_lib.lib().fgnn_count_flags(_ptr(flags), int(flags.shape[0]), _ptr(counts), _stream(self.device)))
+        flags = self._chk(flags, (int(flags.shape[0]),), torch.uint8, "flags")
+        if counts.device != self.device or counts.dtype not in (torch.int64, torch.uint64) or tuple(counts.shape) != (3,) \
+                or not counts.is_contiguous():
+            raise ValueError(f"counts must be a contiguous int64[3] on {self.device}")
+        with torch.cuda.device(self.device):  # fgnn_count_flags takes no graph: it runs on the current device
+            check(_lib.lib().fgnn_count_flags(_ptr(flags), int(flags.shape[0]), _ptr(counts), _stream(self.device)))
         return counts
 
     # ---- Sandwich body -----------------------------------------------------------------------------------
@@ -356,6 +388,10 @@ class TannerGraph:
 
     def sandwich_decode(self, synd_x, synd_z, iters, weights_list, llr_const, factors=None, cn_types=None, compact=False,
                         workspace=None, return_llr=False, return_rounds=False):
+        """fgnn_sandwich_decode.  ``compact=True`` runs each feedback round only on the samples still flagged: ``x_hat`` /
+        ``z_hat`` / ``rounds`` are identical to the full run, but ``llr`` (``return_llr``) of a sample that left the flagged
+        set holds the marginals of the LAST decoder that ran on it, where the full run holds those of the last decoder of the
+        stack (which the reference computes for every sample and then ignores, feedback_gnn.py:336-340)."""
         num_layers = len(iters)
         if len(weights_list) != num_layers - 1:
             raise ValueError("need num_layers-1 feedback GNNs")
@@ -395,22 +431,34 @@ class TannerGraph:
     def compact(self, mask, bit=1):
         """Device index list of the samples with (mask & bit) != 0 and their count (one 4-byte device->host read)."""
         B = int(mask.shape[0])
+        mask = self._chk(mask, (B,), torch.uint8, "mask")
         index = self._new((max(B, 1),), torch.int32)
         count = torch.zeros(1, dtype=torch.int32, device=self.device)
-        check(_lib.lib().fgnn_compact(_ptr(mask), int(bit), B, _ptr(index), _ptr(count), _stream(self.device)))
+        with torch.cuda.device(self.device):
+            check(_lib.lib().fgnn_compact(_ptr(mask), int(bit), B, _ptr(index), _ptr(count), _stream(self.device)))
         return index, int(count.item())
 
     def osd0(self, side, synd, e_hat, marg=None, llr_bin=None, index=None, nact=0):
         """Overwrite e_hat[b] (uint8 [B,n]) for the listed samples with the OSD-0 solution of side 0 (hx) / 1 (hz)."""
         B = int(synd.shape[0])
         synd = self._chk(synd, (B, self.m_x if side == 0 else self.m_z), torch.uint8, "synd")
-        self._chk(e_hat, (B, self.n), torch.uint8, "e_hat")
+        e_hat = self._chk_out(e_hat, (B, self.n), torch.uint8, "e_hat")
+        if marg is not None:
+            marg = self._chk(marg, tuple(marg.shape), torch.float32, "marg")
+        if llr_bin is not None:
+            llr_bin = self._chk(llr_bin, tuple(llr_bin.shape), torch.float32, "llr_bin")
+        if index is not None:
+            index = self._chk(index, tuple(index.shape), torch.int32, "index")
         check(_lib.lib().fgnn_osd0(self.handle, int(side), _ptr(marg), _ptr(llr_bin), _ptr(synd), B, _ptr(index), int(nact),
                                    _ptr(e_hat), _stream(self.device)))
         return e_hat
 
     def residual_rows(self, rows_x, rows_z, ex, ez, x_hat, z_hat):
         B = int(ex.shape[0])
+        ex = self._chk(ex, (B, self.n), torch.uint8, "noise_x")
+        ez = self._chk(ez, (B, self.n), torch.uint8, "noise_z")
+        x_hat = self._chk(x_hat, (B, self.n), torch.uint8, "x_hat")
+        z_hat = self._chk(z_hat, (B, self.n), torch.uint8, "z_hat")
         ls_hat = self._new((B, self._row_count(rows_x) + self._row_count(rows_z)), torch.uint8)
         flags = self._new((B,), torch.uint8)
         check(_lib.lib().fgnn_residual_rows(self.handle, int(rows_x), int(rows_z), _ptr(ex), _ptr(ez), _ptr(x_hat), _ptr(z_hat), B, None,
@@ -439,7 +487,9 @@ class TannerGraph:
 
     def bsc_noise(self, seed, p, first_sample, B):
         e = self._new((B, self.n), torch.uint8)
-        check(_lib.lib().fgnn_bsc_noise(int(seed), float(np.float32(p)), int(first_sample), B, self.n, _ptr(e), _stream(self.device)))
+        with torch.cuda.device(self.device):
+            check(_lib.lib().fgnn_bsc_noise(int(seed), float(np.float32(p)), int(first_sample), B, self.n, _ptr(e),
+                                            _stream(self.device)))
         return e
 
     # ---- GNN_BP4 -----------------------------------------------------------------------------------------
@@ -473,10 +523,10 @@ class GnnBp4Weights:
         if [a.shape for a in arrays] != GNNBP4_SHAPES:
             raise ValueError(f"GNN_BP4 weights must have shapes {GNNBP4_SHAPES}")
         self.arrays = arrays
-        self.device = torch.device(device)
+        self.device = _resolve_device(device)
         ptrs = (C.c_void_p * 30)(*[a.ctypes.data for a in arrays])
         h = C.c_void_p()
-        check(_lib.lib().fgnn_gnnbp4_weights_create(ptrs, 20, 40, self.device.index or 0, C.byref(h)))
+        check(_lib.lib().fgnn_gnnbp4_weights_create(ptrs, 20, 40, self.device.index, C.byref(h)))
         self.handle = h
 
     def __del__(self):

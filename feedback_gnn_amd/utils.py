@@ -17,10 +17,11 @@ def count_block_errors(b, b_hat):
     return (b != b_hat).any(dim=-1).to(torch.int64).sum()
 
 
-def allreduce_counts(counts):
-    """Sum a small integer tensor over all ranks (no-op without an initialised process group)."""
+def allreduce_counts(counts, force=False):
+    """Sum a small integer tensor over all ranks (no-op without an initialised process group, and — unless ``force`` —
+    with a single rank)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size() > 1):
         if counts.is_cuda and dist.get_backend() != "nccl":
             # host-memory backends (gloo: CPU tests, or several ranks sharing one GPU) reduce through a CPU copy
             host = counts.cpu()
@@ -29,6 +30,79 @@ def allreduce_counts(counts):
         else:
             dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     return counts
+
+
+def _require_device_u8(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.dim() == 2 and t.is_contiguous()):
+        raise ValueError(f"{name} must be a contiguous uint8 [B, n] tensor on a HIP device (the bit-pack kernel has no CPU path)")
+
+
+def pack_decisions(x_hat, z_hat):
+    """[B, ceil(2n/8)] uint8 on the same device: row b = the 2n bits [x_hat[b] | z_hat[b]], numpy.packbits order
+    (fgnn_pack_decisions).  2n bits per codeword is what a rank ships when decisions are collected on every rank
+    (318 B per [[1270,28]] codeword)."""
+    import ctypes as C
+    from . import _lib
+    _require_device_u8(x_hat, "x_hat")
+    _require_device_u8(z_hat, "z_hat")
+    if x_hat.shape != z_hat.shape or x_hat.device != z_hat.device:
+        raise ValueError("x_hat and z_hat must have the same shape and device")
+    B, n = int(x_hat.shape[0]), int(x_hat.shape[1])
+    packed = torch.empty((B, (2 * n + 7) // 8), dtype=torch.uint8, device=x_hat.device)
+    with torch.cuda.device(x_hat.device):
+        _lib.check(_lib.lib().fgnn_pack_decisions(C.c_void_p(x_hat.data_ptr()), C.c_void_p(z_hat.data_ptr()), B, n,
+                                                  C.c_void_p(packed.data_ptr()),
+                                                  C.c_void_p(torch.cuda.current_stream(x_hat.device).cuda_stream)))
+    return packed
+
+
+def unpack_decisions(packed, n):
+    """Inverse of `pack_decisions`: (x_hat, z_hat) uint8 [B, n] on the device of ``packed`` (fgnn_unpack_decisions)."""
+    import ctypes as C
+    from . import _lib
+    _require_device_u8(packed, "packed")
+    B, n = int(packed.shape[0]), int(n)
+    if packed.shape[1] != (2 * n + 7) // 8:
+        raise ValueError(f"packed must have {(2 * n + 7) // 8} bytes per codeword for n = {n}")
+    x_hat = torch.empty((B, n), dtype=torch.uint8, device=packed.device)
+    z_hat = torch.empty((B, n), dtype=torch.uint8, device=packed.device)
+    with torch.cuda.device(packed.device):
+        _lib.check(_lib.lib().fgnn_unpack_decisions(C.c_void_p(packed.data_ptr()), B, n, C.c_void_p(x_hat.data_ptr()),
+                                                    C.c_void_p(z_hat.data_ptr()),
+                                                    C.c_void_p(torch.cuda.current_stream(packed.device).cuda_stream)))
+    return x_hat, z_hat
+
+
+def gather_packed(packed):
+    """All-gather of per-rank rows ``packed [B_r, nb]`` (uint8) in rank order onto every rank: ``[sum_r B_r, nb]``.  One
+    `all_gather_into_tensor` (RCCL over xGMI with the nccl backend); ranks may own different numbers of rows (the shard sizes
+    of `shard_range` differ by at most one) — then the rows are padded to the largest shard for the collective and the padding is
+    dropped afterwards.  Without a process group (or with world size 1 and no group) the input is returned unchanged."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return packed
+    world = dist.get_world_size()
+    via_host = packed.is_cuda and dist.get_backend() != "nccl"  # gloo: several ranks sharing one GPU, or the CPU tests
+    buf = packed.cpu() if via_host else packed
+    sizes = torch.zeros(world, dtype=torch.int64, device=buf.device)
+    mine = torch.tensor([buf.shape[0]], dtype=torch.int64, device=buf.device)
+    dist.all_gather_into_tensor(sizes, mine)
+    sizes = [int(v) for v in sizes.cpu()]
+    most, nb = max(sizes), int(buf.shape[1])
+    if buf.shape[0] < most:
+        buf = torch.cat([buf, torch.zeros((most - buf.shape[0], nb), dtype=buf.dtype, device=buf.device)])
+    out = torch.empty((world * most, nb), dtype=buf.dtype, device=buf.device)
+    dist.all_gather_into_tensor(out, buf.contiguous())
+    if any(sz != most for sz in sizes):
+        out = torch.cat([out[r * most:r * most + sizes[r]] for r in range(world)])
+    return out.to(packed.device) if via_host else out
+
+
+def gather_decisions(x_hat, z_hat):
+    """Decisions of ALL ranks on every rank, in rank (= global sample) order: ``(x_hat_all, z_hat_all)`` uint8
+    ``[sum_r B_r, n]``.  The ranks exchange 2n bits per codeword: bit-pack kernel -> one all-gather -> unpack kernel."""
+    n = int(x_hat.shape[1])
+    return unpack_decisions(gather_packed(pack_decisions(x_hat, z_hat)), n)
 
 
 def shard_range(total, rank, world_size):
@@ -40,11 +114,19 @@ def shard_range(total, rank, world_size):
 
 def sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=False, num_target_bit_errors=None,
             num_target_block_errors=None, early_stop=True, graph_mode=None, verbose=True,
-            forward_keyboard_interrupt=True, qldpc=True, dist=False, dtype=None):
+            forward_keyboard_interrupt=True, qldpc=True, dist=False, dtype=None, device_counters=True, max_deferred=64):
     """Simulate until the target number of errors is reached; returns (flagged_rate, bler) per point.
 
     Only the ``qldpc=True`` branch of the reference exists here: ``mc_fun(batch_size=, ebno_db=)`` returns
-    ``(s_hat, ls_hat)`` and a block counts as flagged / as a block error iff its row is non-zero.
+    ``(s_hat, ls_hat)`` and a block counts as flagged / as a block error iff its row is non-zero (misc.py:636-738).
+
+    Device-counter path (``device_counters=True`` and ``mc_fun`` offers ``mc_step(batch_size, p, counts)`` and
+    ``rewind(batches, batch_size)``, as `Sandwich_BP_GNN_Evaluation_Model` does): the three counters stay on the device,
+    every batch leaves a snapshot of them in a device ring, and the host reads the ring back (one copy, one all-reduce with
+    ``dist=True``) only when the target could have been reached — after the first batch, then after as many batches as the
+    measured error rate predicts, at most ``max_deferred``.  The stopping rule is then applied to the snapshots IN ORDER, so
+    the point ends after exactly the batch at which the per-batch loop of the reference would have ended; batches run beyond
+    it are discarded and the model's sample stream is rewound, so every counter of every point equals the per-batch path's.
     """
     if not qldpc:
         raise NotImplementedError("only the qldpc=True branch of sim_ber is part of this package")
@@ -58,6 +140,8 @@ def sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=False, num
     names = ["not simulated", "reached max iter       ", "no errors - early stop", "reached target bit errors",
              "reached target block errors"]
     header = ["p", "Flagged", "BLER", "flag errors", "block errors", "num blocks", "runtime [s]", "status"]
+    fast = bool(device_counters) and hasattr(mc_fun, "mc_step") and hasattr(mc_fun, "rewind")
+    max_it = int(max_mc_iter)
 
     def row(i, st):
         fl = flag_errors[i] / max(nb_blocks[i], 1)
@@ -65,33 +149,84 @@ def sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=False, num
         return (f"{ps[i]:9.4g} | {fl:10.4e} | {bl:10.4e} | {flag_errors[i]:11d} | {block_errors[i]:12d} | "
                 f"{nb_blocks[i]:11d} | {runtime[i]:11.1f} |{st}")
 
+    def stop_status(c, it):
+        """Status after a batch whose cumulative counters are c (the reference's checks, misc.py:700-738), 0 = go on."""
+        if num_target_bit_errors is not None and c[0] >= num_target_bit_errors:
+            return 3
+        if num_target_block_errors is not None and c[1] >= num_target_block_errors:
+            return 4
+        return 1 if it == max_it - 1 else 0
+
+    def run_point_per_batch(i, t0):
+        for it in range(max_it):
+            s_hat, l_hat = mc_fun(batch_size=batch_size, ebno_db=ps[i])[:2]
+            c = torch.stack([count_block_errors(torch.zeros_like(s_hat), s_hat),
+                             count_block_errors(torch.zeros_like(l_hat), l_hat),
+                             torch.tensor(s_hat.shape[0], dtype=torch.int64, device=s_hat.device)])
+            if dist:
+                c = allreduce_counts(c)
+            c = c.cpu().numpy()
+            flag_errors[i] += c[0]
+            block_errors[i] += c[1]
+            nb_blocks[i] += c[2]
+            runtime[i] = time.perf_counter() - t0
+            st = stop_status((flag_errors[i], block_errors[i]), it)
+            if st:
+                status[i] = st
+                break
+
+    def run_point_device(i, t0):
+        counts = None
+        ring = None
+        it = 0       # batches issued
+        done = 0     # batches whose snapshot the host has seen
+        k = 1
+        while it < max_it:
+            k = max(1, min(k, max_it - it, int(max_deferred)))
+            for j in range(k):
+                if counts is None:
+                    probe = mc_fun.mc_step(batch_size, ps[i], None)  # allocates the device counters on the model's device
+                    counts = probe
+                    ring = torch.zeros((int(max_deferred), 3), dtype=torch.int64, device=counts.device)
+                else:
+                    mc_fun.mc_step(batch_size, ps[i], counts)
+                ring[j].copy_(counts)
+            it += k
+            snap = ring[:k].clone()
+            if dist:
+                snap = allreduce_counts(snap)
+            snap = snap.cpu().numpy()  # the only host synchronisation of these k batches
+            ended = False
+            for j in range(k):
+                st = stop_status(snap[j], done + j)
+                if st:
+                    flag_errors[i], block_errors[i], nb_blocks[i] = snap[j]
+                    status[i] = st
+                    if k - 1 - j:
+                        mc_fun.rewind(k - 1 - j, batch_size)  # batches issued beyond the one the point ends with
+                    ended = True
+                    break
+            runtime[i] = time.perf_counter() - t0
+            if ended:
+                return
+            flag_errors[i], block_errors[i], nb_blocks[i] = snap[k - 1]
+            done += k
+            # next read-back when the nearer target is expected to be reached, from the rate seen so far
+            want = []
+            if num_target_bit_errors is not None:
+                want.append((num_target_bit_errors - flag_errors[i]) / max(flag_errors[i] / done, 1e-9))
+            if num_target_block_errors is not None:
+                want.append((num_target_block_errors - block_errors[i]) / max(block_errors[i] / done, 1e-9))
+            k = int(min(want)) if want else int(max_deferred)
+            k = max(1, min(k, 4 * done))  # never commit to more than 4x what has been seen
+
     try:
         for i in range(n_pts):
             t0 = time.perf_counter()
-            it = -1
-            for it in range(int(max_mc_iter)):
-                s_hat, l_hat = mc_fun(batch_size=batch_size, ebno_db=ps[i])[:2]
-                c = torch.stack([count_block_errors(torch.zeros_like(s_hat), s_hat),
-                                 count_block_errors(torch.zeros_like(l_hat), l_hat),
-                                 torch.tensor(s_hat.shape[0], dtype=torch.int64, device=s_hat.device)])
-                if dist:
-                    c = allreduce_counts(c)
-                c = c.cpu().numpy()
-                flag_errors[i] += c[0]
-                block_errors[i] += c[1]
-                nb_blocks[i] += c[2]
-                runtime[i] = time.perf_counter() - t0
-                if verbose and i == 0 and it == 0:
-                    print(" | ".join(f"{h:>11s}" for h in header))
-                    print("-" * 135)
-                if num_target_bit_errors is not None and flag_errors[i] >= num_target_bit_errors:
-                    status[i] = 3
-                    break
-                if num_target_block_errors is not None and block_errors[i] >= num_target_block_errors:
-                    status[i] = 4
-                    break
-                if it == int(max_mc_iter) - 1:
-                    status[i] = 1
+            if verbose and i == 0:
+                print(" | ".join(f"{h:>11s}" for h in header))
+                print("-" * 135)
+            (run_point_device if fast else run_point_per_batch)(i, t0)
             if verbose:
                 print(row(i, names[status[i]]))
             if early_stop and block_errors[i] == 0:
@@ -107,7 +242,7 @@ def sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=False, num
         flagged = np.where(nb_blocks > 0, flag_errors / np.maximum(nb_blocks, 1), 0.0)
         bler = np.where(nb_blocks > 0, block_errors / np.maximum(nb_blocks, 1), 0.0)
     sim_ber.last = dict(p=ps, flag_errors=flag_errors, block_errors=block_errors, num_blocks=nb_blocks, runtime=runtime,
-                        status=status)
+                        status=status, device_counters=fast)
     return flagged, bler
 
 
@@ -122,11 +257,12 @@ class PlotBER:
     def simulate(self, mc_fun, ebno_dbs, batch_size, max_mc_iter, legend="", add_ber=True, add_bler=False,
                  soft_estimates=False, num_target_bit_errors=None, num_target_block_errors=None, early_stop=True,
                  graph_mode=None, add_results=True, forward_keyboard_interrupt=True, show_fig=False, verbose=True,
-                 qldpc=True, dist=False):
+                 qldpc=True, dist=False, device_counters=True):
         flagged, bler = sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=soft_estimates,
                                 num_target_bit_errors=num_target_bit_errors,
                                 num_target_block_errors=num_target_block_errors, early_stop=early_stop, verbose=verbose,
-                                forward_keyboard_interrupt=forward_keyboard_interrupt, qldpc=qldpc, dist=dist)
+                                forward_keyboard_interrupt=forward_keyboard_interrupt, qldpc=qldpc, dist=dist,
+                                device_counters=device_counters)
         if add_results:
             ps = np.atleast_1d(np.asarray(ebno_dbs, dtype=np.float64))
             if add_ber:

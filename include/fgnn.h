@@ -160,6 +160,11 @@ int fgnn_residual(const fgnn_graph* g, const uint8_t* noise_x, const uint8_t* no
  * BP4_OSD_Model.call, bp_osd.py:184-188. */
 int fgnn_residual_rows(const fgnn_graph* g, int rows_x, int rows_z, const uint8_t* noise_x, const uint8_t* noise_z,
                        const uint8_t* x_hat, const uint8_t* z_hat, int B, uint8_t* s_hat, uint8_t* ls_hat, uint8_t* flags, void* stream);
+/* Bit-packed decisions for the multi-GPU gather (no reference equivalent: the reference runs one process per GPU id and
+ * never collects decisions, n882.py:9,15-21): packed[b] = the 2n bits [x_hat[b,:] | z_hat[b,:]], most significant bit first
+ * (numpy.packbits order), ceil(2n/8) bytes per codeword; fgnn_unpack_decisions is the inverse.  Runs on the current device. */
+int fgnn_pack_decisions(const uint8_t* x_hat, const uint8_t* z_hat, int B, int n, uint8_t* packed, void* stream);
+int fgnn_unpack_decisions(const uint8_t* packed, int B, int n, uint8_t* x_hat, uint8_t* z_hat, void* stream);
 /* counts[0] += #flagged, counts[1] += #block errors, counts[2] += B (device uint64[3]), misc.py:649-669. */
 int fgnn_count_flags(const uint8_t* flags, int B, uint64_t* counts, void* stream);
 

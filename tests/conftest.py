@@ -19,6 +19,5 @@ def _built_libraries():
     from oracle import oracle as _o
     _o.build()
     from feedback_gnn_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
-        _lib.build()
+    _lib.build()  # make is incremental: a no-op when up to date, a rebuild after any edit of csrc/ (never a stale binary)
     yield

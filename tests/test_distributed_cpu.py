@@ -14,10 +14,10 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from feedback_gnn_amd.utils import allreduce_counts, shard_range
+from feedback_gnn_amd.utils import allreduce_counts, gather_packed, shard_range
 from helpers import llr_const, oracle_graph
 
-TOTAL, P, SEED = 600, 0.09, 0x5EED
+TOTAL, P, SEED = 601, 0.09, 0x5EED  # odd: the two shards differ by one row
 
 
 def _counts_for(lo, hi):
@@ -38,14 +38,10 @@ def _worker(rank, world, port, q):
         lo, hi = shard_range(TOTAL, rank, world)
         c, packed = _counts_for(lo, hi)
         counts = allreduce_counts(torch.from_numpy(c.copy()))
-        # optional gather of bit-packed decisions (2n bits per codeword) onto every rank
-        mine = torch.from_numpy(packed)
-        sizes = [shard_range(TOTAL, r, world)[1] - shard_range(TOTAL, r, world)[0] for r in range(world)]
-        bufs = [torch.empty((s, mine.shape[1]), dtype=torch.uint8) for s in sizes]
-        dist.all_gather(bufs, mine) if len(set(sizes)) == 1 else [dist.broadcast(bufs[r] if r != rank else mine, r) for r in range(world)]
-        if len(set(sizes)) != 1:
-            bufs[rank] = mine
-        q.put((rank, counts.numpy().copy(), torch.cat(bufs).numpy().copy()))
+        # product all-gather of the bit-packed decisions (2n bits per codeword) onto every rank, uneven shards included;
+        # the rows are packed by numpy here (the HIP bit-pack kernel is covered on the GPU box, tests/test_gpu_rccl.py)
+        gathered = gather_packed(torch.from_numpy(packed))
+        q.put((rank, counts.numpy().copy(), gathered.numpy().copy()))
     finally:
         dist.destroy_process_group()
 

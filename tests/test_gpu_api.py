@@ -144,6 +144,26 @@ def test_sim_ber_on_gpu_reaches_target():
     assert 0.3 < bler[0] < 0.85 and 0.03 < bler[1] < 0.3
 
 
+def test_sim_ber_device_counters_equal_the_per_batch_path():
+    """misc.py:636-738 on the product's fast path: counters stay on the device, the host reads a ring of per-batch snapshots only
+    when the target could have been reached, and the stopping rule is applied to the snapshots in order — flag errors, block
+    errors, block counts and status of every point equal the per-batch (array-returning) path's, compact or not."""
+    c = code("ghp882")
+    for compact in (False, True):
+        ref_m, fast_m = _model(c, [64, 16], compact=compact), _model(c, [64, 16], compact=compact)
+        F.sim_ber(ref_m, [0.13, 0.11, 0.09], batch_size=1500, max_mc_iter=12, num_target_block_errors=100, verbose=False,
+                  early_stop=False, device_counters=False)
+        ref = {k: np.array(v).copy() for k, v in F.sim_ber.last.items()}
+        assert not F.sim_ber.last["device_counters"]
+        F.sim_ber(fast_m, [0.13, 0.11, 0.09], batch_size=1500, max_mc_iter=12, num_target_block_errors=100, verbose=False,
+                  early_stop=False)
+        assert F.sim_ber.last["device_counters"]
+        for k in ("flag_errors", "block_errors", "num_blocks", "status"):
+            assert np.array_equal(ref[k], F.sim_ber.last[k]), (compact, k, ref[k], F.sim_ber.last[k])
+        assert ref_m._next_sample == fast_m._next_sample
+        assert ref["status"][0] == 4 and ref["status"][2] == 1  # a point that reaches the target and one that hits max iter
+
+
 def test_fixed_weight_noise_and_failure_harvesting():
     """Pauli(wt=True) (pauli.py:80-97) and the dataset-harvesting flow of examples/Generate_dataset.ipynb."""
     c = code("ghp882")

@@ -107,6 +107,56 @@ def test_count_block_errors_and_sim_ber_qldpc():
         sim_ber(mc_fun, [0.1], 10, 1, qldpc=False)
 
 
+class _StreamModel:
+    """Host stand-in with the model surface sim_ber's device-counter path needs: a counter-based sample stream (sample i is a
+    pure function of i, like the Philox stream of the product), the per-batch call, mc_step and rewind."""
+
+    def __init__(self):
+        self._next = 0
+        self.issued = 0
+
+    def _rows(self, batch_size, p):
+        idx = np.arange(self._next, self._next + batch_size, dtype=np.uint64)
+        self._next += batch_size
+        self.issued += 1
+        h = (idx * np.uint64(0x9E3779B97F4A7C15) >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+        fl = (h < p).astype(np.uint8)
+        lg = (h < p / 3).astype(np.uint8)
+        return torch.from_numpy(fl[:, None]), torch.from_numpy(np.stack([fl, lg], axis=1))
+
+    def __call__(self, batch_size, ebno_db):
+        return self._rows(batch_size, ebno_db)
+
+    def mc_step(self, batch_size, p, counts=None):
+        if counts is None:
+            counts = torch.zeros(3, dtype=torch.int64)
+        s, l = self._rows(batch_size, p)
+        counts += torch.tensor([int(s.any(1).sum()), int(l.any(1).sum()), batch_size])
+        return counts
+
+    def rewind(self, batches, batch_size):
+        self._next -= batches * batch_size
+
+
+def test_sim_ber_device_counter_path_equals_per_batch_path():
+    """The deferred read-back must end every point after exactly the batch the per-batch loop ends it with, and leave the
+    sample stream where that loop leaves it (so later points see the same samples): identical counters and status for every
+    point, with far fewer host read-backs than batches."""
+    pts = [0.3, 0.05, 0.01, 0.002]
+    for kw in (dict(num_target_block_errors=100), dict(num_target_bit_errors=40), dict(num_target_block_errors=100000)):
+        a, b = _StreamModel(), _StreamModel()
+        sim_ber(a, pts, batch_size=64, max_mc_iter=300, verbose=False, early_stop=False, device_counters=False, **kw)
+        ref = {k: np.array(v).copy() for k, v in sim_ber.last.items()}
+        assert ref["device_counters"] is not None and not sim_ber.last["device_counters"]
+        sim_ber(b, pts, batch_size=64, max_mc_iter=300, verbose=False, early_stop=False, device_counters=True,
+                max_deferred=16, **kw)
+        assert sim_ber.last["device_counters"]
+        for k in ("flag_errors", "block_errors", "num_blocks", "status"):
+            assert np.array_equal(ref[k], sim_ber.last[k]), (kw, k, ref[k], sim_ber.last[k])
+        assert a._next == b._next  # the stream position after the run is the per-batch loop's
+    assert b.issued >= a.issued  # discarded batches are the price; the counters are not affected
+
+
 def test_shard_range_partitions_exactly():
     for total, world in ((10, 3), (65536, 8), (7, 8), (262144, 8)):
         spans = [shard_range(total, r, world) for r in range(world)]
