@@ -114,7 +114,10 @@ def launch_ranks(args, argv):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     out0, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+    # rank 0's stdout carries the ONE JSON line; anything else a library printed there (gloo's rendezvous banner) goes to stderr
+    for line in out0.splitlines():
+        is_json = line.lstrip().startswith("{") and line.rstrip().endswith("}")
+        (sys.stdout if is_json else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
