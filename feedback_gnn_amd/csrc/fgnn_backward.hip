@@ -72,6 +72,7 @@ struct BwArgs {
 // One workgroup per codeword.  LDS: mu[E] | nu[max(E,2n)] | dmu[E] | tot[3n] | dtot[3n] | coef[rows0+rows1].
 __global__ void __launch_bounds__(256) bp4_backward_kernel(GraphDev g, BwArgs a)
 {
+    FG_LOG_TAB_SETUP();
     extern __shared__ float lds[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int n = g.n, E = g.E;
@@ -400,7 +401,7 @@ extern "C" int fgnn_bp4_backward(const fgnn_graph* g, int num_iter, float normal
     a.dllr = grad_llr_ch;
     const size_t floats = (size_t)2 * d.E + a.nu_sz + (size_t)6 * d.n + d.rows[0] + d.rows[1];
     const size_t lds_bytes = floats * sizeof(float);
-    if (lds_bytes > 160 * 1024) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident backward kernel");
+    if (lds_bytes > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident backward kernel");
     auto kern = bp4_backward_kernel;
     if (lds_bytes > 48 * 1024)
         FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -448,7 +449,7 @@ extern "C" int fgnn_feedback_gnn_backward(const fgnn_graph* g, const fgnn_weight
         a.e_dm[s] = edge_dm[s];
     }
     const size_t lds_bytes = (size_t)g->d.m * sizeof(float);
-    if (lds_bytes > 160 * 1024) return fgnn_fail(FGNN_ERR_ARG, "too many checks for the LDS-resident kernel");
+    if (lds_bytes > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "too many checks for the LDS-resident kernel");
     auto kern = gnn_backward_kernel;
     if (lds_bytes > 48 * 1024)
         FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

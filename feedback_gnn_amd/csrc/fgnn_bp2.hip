@@ -102,6 +102,7 @@ __device__ __forceinline__ void cn_update2(float* msg, const int* __restrict__ s
 template <int CN_TYPE>
 __global__ void __launch_bounds__(1024) bp2_kernel(GraphDev g, Bp2Args a)
 {
+    FG_LOG_TAB_SETUP();
     extern __shared__ float lds[];
     const int cwl = threadIdx.x / a.tpc;
     const int lane = threadIdx.x - cwl * a.tpc;
@@ -192,7 +193,7 @@ extern "C" int fgnn_bp2_decode(const fgnn_graph* g, int cn_type, int num_iter, f
     a.hard_out = hard_out;
     a.lds_per_cw = (g->d.E_x + 3) & ~3;
     const size_t lds_bytes = (size_t)a.lds_per_cw * sizeof(float) * (size_t)L.cpb;
-    if (lds_bytes > 160 * 1024) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident kernel");
+    if (lds_bytes > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident kernel");
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (cn_type) {
     case FGNN_CN_BOXPLUS_PHI: return launch<FGNN_CN_BOXPLUS_PHI>(g, a, L, lds_bytes, st);

@@ -236,6 +236,7 @@ __device__ __forceinline__ float softplus_saturated(float t)
 template <int CN_TYPE, int DVX, int DVZ, int DC, bool OPT>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) bp4_kernel(GraphDev g, BpArgs a)
 {
+    FG_LOG_TAB_SETUP();
     constexpr bool REGULAR = DVX > 0;
     const bool opt_shortcut = OPT && a.shortcut != 0;
     const bool opt_exit = OPT && a.early_exit != 0;
@@ -632,7 +633,7 @@ int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float n
     a.sig_off = per_cw;
     if (a.early_exit) {
         const size_t with_det = lds_bytes + ((size_t)g->d.n + 4) * sizeof(float);
-        if (with_det <= 160 * 1024) lds_bytes = with_det;
+        if (with_det <= FGNN_LDS_BUDGET) lds_bytes = with_det;
         else a.early_exit = 0;
     }
     a.flagged = flagged;
@@ -642,7 +643,7 @@ int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float n
         a.flag_off = (int)(lds_bytes / sizeof(float));
         lds_bytes += (size_t)((g->d.n + 3) & ~3) + sizeof(unsigned);
     }
-    if (lds_bytes > 160 * 1024) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident kernel");
+    if (lds_bytes > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident kernel");
     hipStream_t st = static_cast<hipStream_t>(stream);
     fgnn_prof_scope prof(g, st);
     int rc;

@@ -141,6 +141,7 @@ struct Args {
 
 __global__ void __launch_bounds__(256) gnn_bp4_kernel(GraphDev g, GnnBp4Dev w, Args a)
 {
+    FG_LOG_TAB_SETUP();
     extern __shared__ float lds[];
     const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
     const int n = g.n, mx = g.m_x, m = g.m;
@@ -279,6 +280,7 @@ __global__ void __launch_bounds__(256) gnn_bp4_kernel(GraphDev g, GnnBp4Dev w, A
 template <int DV, int DC>
 __global__ void __launch_bounds__(512, 2) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4Dev w, Args a, int tab_floats)
 {
+    FG_LOG_TAB_SETUP();
     // LDS: [tab_floats] the current phase's per-lane operand tables (staged from L2 at every phase start: operand
     // reads then cost an LDS access instead of an L2 round trip, which is what the waves were waiting on), then
     // lx | lz | hlog.  512 threads = 8 waves share the staged tables; two workgroups fit a CU.
@@ -591,7 +593,7 @@ extern "C" int fgnn_gnnbp4_decode(const fgnn_graph* g, const fgnn_gnnbp4_weights
         const int tab_floats = (cn_entries > vn_entries ? cn_entries : vn_entries) * 64;
         const size_t lds2 = lds_bytes + (size_t)tab_floats * sizeof(float);
         auto kern = gnn_bp4_mfma_kernel<3, 6>;
-        if (lds2 > 160 * 1024) return fgnn_fail(FGNN_ERR_ARG, "code too large for the GNN_BP4 MFMA kernel");
+        if (lds2 > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "code too large for the GNN_BP4 MFMA kernel");
         FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds2, static_cast<hipStream_t>(stream), g->d, w->d, a, tab_floats);
         FGNN_HIP_CHECK(hipGetLastError());

@@ -138,6 +138,9 @@ struct fgnn_prof_scope {
     }
 };
 
+// dynamic LDS a kernel may ask for: the CU's 160 KB minus the 256-byte log table of fgnn_math.h (static LDS)
+constexpr size_t FGNN_LDS_BUDGET = 160 * 1024 - 256;
+
 // launch geometry shared by the per-codeword kernels
 struct LaunchGeom {
     int tpc, cpb, threads, blocks;

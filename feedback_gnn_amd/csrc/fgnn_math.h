@@ -7,7 +7,7 @@
  *   - by gcc    (-ffp-contract=off -mfma) into the CPU oracle (the .c files under oracle),
  * so a GPU result and an oracle result are the same bits, for every sample and every iteration.
  * Accuracy (tools/check_math.c, exhaustive over the domains used): exp <= 0.9 ulp,
- * log <= 0.93 ulp, log1p <= 1.5 ulp, tanh <= 2.7 ulp — the same class as TensorFlow's own Eigen / XLA kernels,
+ * log <= 1.2 ulp, log1p <= 1.3 ulp, tanh <= 2.7 ulp — the same class as TensorFlow's own Eigen / XLA kernels,
  * which are not correctly rounded either (SURVEY.md §8c "Third-party arithmetic").
  *
  * The composite functions restate TensorFlow op semantics used by the reference:
@@ -80,52 +80,89 @@ FG_FN float fg_exp(float x)
 }
 
 /* ---- log -------------------------------------------------------------------------------- */
-/* log(2^e * (1+f)) for f in [sqrt(.5)-1, sqrt(2)-1], ef = (float)e.
- * log1p(f) = f - f^2/2 + f^3*P7(f).  12 VALU ops. */
-FG_FN float fg_log_core(float f, float ef)
+/* Table-driven: x = 2^e * m with m in [0.7109375, 1.421875); m is rounded to the nearest point c of the float grid with five
+ * mantissa bits (46/64 .. 63/64 below 1, 32/32 .. 45/32 from 1 on: 32 points, index j), and
+ *     log(x) = e*ln2 + LC[j] + log1p(r),   r = m*RC[j] - 1,  |r| <= 1/64,   log1p(r) = r + r^2*(c0 + c1 r + c2 r^2).
+ * RC[j] is a float near 1/c chosen so that LC[j] = -log(RC[j]) is a float to 2^-11 ulp (tools/gen_log_table.py), so no low
+ * word is needed; c = 1 has RC = 1, LC = 0 exactly, which keeps full relative accuracy around x = 1.  13 VALU ops and one
+ * two-dword table read on gfx950 (the polynomial-only version was 18 ops).  On the device the two 32-entry arrays live in 64
+ * consecutive LDS words — entry j of either array sits in bank j, so a wave's lookup is conflict-free whatever the indices —
+ * and every kernel that evaluates a log calls FG_LOG_TAB_SETUP() first.  The CPU reads the same numbers from a static array. */
+#define FG_LOG_TAB_INIT                                                                                                          \
+    {                                                                                                                            \
+        1.390858173e+00f, 1.361959696e+00f, 1.333572030e+00f, 1.306513667e+00f, 1.280209303e+00f, 1.255162835e+00f,              \
+            1.230969906e+00f, 1.207589507e+00f, 1.185119271e+00f, 1.163626194e+00f, 1.142805934e+00f, 1.123076320e+00f,          \
+            1.103107095e+00f, 1.084379315e+00f, 1.066453695e+00f, 1.049526930e+00f, 1.032514930e+00f, 1.016141653e+00f,          \
+            1.000000000e+00f, 9.695707560e-01f, 9.413171411e-01f, 9.144760966e-01f, 8.888078928e-01f, 8.649825454e-01f,          \
+            8.420355916e-01f, 8.206610680e-01f, 8.001205921e-01f, 7.804491520e-01f, 7.619996667e-01f, 7.444245219e-01f,          \
+            7.273896933e-01f, 7.110862732e-01f, /* LC = -log(RC) */                                                              \
+            -3.299209476e-01f, -3.089246154e-01f, -2.878610790e-01f, -2.673622668e-01f, -2.470235825e-01f, -2.272653133e-01f,    \
+            -2.078024000e-01f, -1.886262298e-01f, -1.698434204e-01f, -1.515411586e-01f, -1.334865838e-01f, -1.160716340e-01f,    \
+            -9.813082963e-02f, -8.100776374e-02f, -6.433884054e-02f, -4.833951965e-02f, -3.199750558e-02f, -1.601276174e-02f,    \
+            0.000000000e+00f, 3.090182506e-02f, 6.047517061e-02f, 8.940394968e-02f, 1.178741604e-01f, 1.450459510e-01f,          \
+            1.719329953e-01f, 1.976450831e-01f, 2.229928225e-01f, 2.478856891e-01f, 2.718091607e-01f, 2.951438129e-01f,          \
+            3.182929158e-01f, 3.409615159e-01f                                                                                   \
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+static __constant__ float fg_log_tab_const[64] = FG_LOG_TAB_INIT;
+static __device__ __forceinline__ float* fg_log_tab(void)
 {
-    float z = f * f;
-    float p = -7.634429634e-02f;
-    p = FG_FMA(p, f, 1.276154965e-01f);
-    p = FG_FMA(p, f, -1.316019446e-01f);
-    p = FG_FMA(p, f, 1.420176178e-01f);
-    p = FG_FMA(p, f, -1.662335694e-01f);
-    p = FG_FMA(p, f, 2.000122666e-01f);
-    p = FG_FMA(p, f, -2.500082254e-01f);
-    p = FG_FMA(p, f, 3.333333135e-01f);
-    float u = FG_FMA(f, p, -0.5f);
-    float r = FG_FMA(z, u, f);
-    r = FG_FMA(ef, FG_LN2_LO, r);
-    return FG_FMA(ef, FG_LN2_HI, r);
+    __shared__ float tab[64];
+    return tab;
+}
+/* first statement of every kernel that evaluates fg_log / fg_log1p / fg_softplus / fg_lse2 / fg_phi / fg_atanh */
+#define FG_LOG_TAB_SETUP()                                                          \
+    do {                                                                            \
+        for (int i_ = threadIdx.x; i_ < 64; i_ += blockDim.x) fg_log_tab()[i_] = fg_log_tab_const[i_]; \
+        __syncthreads();                                                            \
+    } while (0)
+#else
+static const float fg_log_tab_host[64] = FG_LOG_TAB_INIT;
+FG_FN const float* fg_log_tab(void) { return fg_log_tab_host; }
+#define FG_LOG_TAB_SETUP() ((void)0)
+#endif
+#define FG_LOG_OFFS 0x3f360000u          /* bits(0.71875) - half a grid step: rounds m to the nearest grid point */
+#define FG_LN2_S23 8.26295832e-08f       /* RN(ln 2) * 2^-23: the exponent arrives as e << 23 */
+#define FG_L1P_C0 -0.5f
+#define FG_L1P_C1 3.333737850e-01f
+#define FG_L1P_C2 -2.500432432e-01f
+
+/* r + r^2*(c0 + c1 r + c2 r^2), |r| <= 1/64: relative error 0.035 ulp */
+FG_FN float fg_log1p_small(float r)
+{
+    float p = FG_FMA(r, FG_L1P_C2, FG_L1P_C1);
+    p = FG_FMA(r, p, FG_L1P_C0);
+    return FG_FMA(r * r, p, r);
 }
 
 /* log(x) for normal positive x. */
 FG_FN float fg_log(float x)
 {
-    uint32_t ix = fg_f2u(x) - FG_SQRT_HALF_BITS;
-    int32_t e = (int32_t)ix >> 23;
-    float m = fg_u2f((ix & 0x007fffffu) + FG_SQRT_HALF_BITS); /* m in [sqrt(.5), sqrt(2)) */
-    return fg_log_core(m - 1.0f, (float)e);
+    const float* tab = fg_log_tab();
+    const uint32_t b = fg_f2u(x);
+    const uint32_t w = b - FG_LOG_OFFS;
+    const uint32_t eb = w & 0xff800000u;              /* e << 23 */
+    const float mm = fg_u2f(b - eb);                  /* x * 2^-e in [0.7109375, 1.421875) */
+    const uint32_t j = (w >> 18) & 31u;
+    const float rc = tab[j], lc = tab[32 + j];
+    const float r = FG_FMA(mm, rc, -1.0f);
+    const float ef = (float)(int32_t)eb;              /* e * 2^23 */
+    return FG_FMA(ef, FG_LN2_S23, lc + fg_log1p_small(r));
 }
 
-/* log(w) for w in [1, 2]: same bits as fg_log(w) (same reduced argument, same core), cheaper split. */
-FG_FN float fg_log_1to2(float w)
-{
-    int big = w >= 1.41421354f; /* bits 0x3fb504f3 = 2*sqrt(.5): fg_log switches exponent here too */
-    float m = big ? 0.5f * w : w;
-    return fg_log_core(m - 1.0f, big ? 1.0f : 0.0f);
-}
-
-/* log(1+u) for u in [0, 2^24].  The exponent e is read from RN(1+u); the reduced argument
- * f = (1+u)*2^-e - 1 is then formed by ONE fma from u itself, so no bits of u are lost. */
+/* log(1+u) for u in [0, 2^24].  Grid point and exponent are read from RN(1+u); the reduced argument
+ * r = (1+u)*2^-e*RC - 1 is then formed by ONE fma from u itself, so no bits of a small u are lost. */
 FG_FN float fg_log1p(float u)
 {
-    float w = 1.0f + u;
-    uint32_t ix = fg_f2u(w) - FG_SQRT_HALF_BITS;
-    int32_t e = (int32_t)ix >> 23;
-    float sc = fg_u2f(0x3f800000u - (ix & 0xff800000u)); /* 2^-e */
-    float f = FG_FMA(u, sc, sc - 1.0f);
-    return fg_log_core(f, (float)e);
+    const float* tab = fg_log_tab();
+    const uint32_t w = fg_f2u(1.0f + u) - FG_LOG_OFFS;
+    const uint32_t eb = w & 0xff800000u;
+    const uint32_t j = (w >> 18) & 31u;
+    const float rc = tab[j], lc = tab[32 + j];
+    const float a = fg_u2f(fg_f2u(rc) - eb);          /* RC * 2^-e */
+    const float r = FG_FMA(u, a, a - 1.0f);
+    const float ef = (float)(int32_t)eb;
+    return FG_FMA(ef, FG_LN2_S23, lc + fg_log1p_small(r));
 }
 
 /* ---- TensorFlow op restatements ----------------------------------------------------------- */
@@ -148,7 +185,7 @@ FG_FN float fg_lse2(float a, float b)
     float m = FG_MAX(a, b);
     float d = FG_ABS(a - b);
     float y = fg_exp(-FG_MIN(d, 20.0f));
-    return fg_log_1to2(1.0f + y) + m;
+    return fg_log(1.0f + y) + m;
 }
 
 /* QLDPCBPDecoder._phi, decoding_q.py:365-373:

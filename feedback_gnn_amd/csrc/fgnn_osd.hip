@@ -27,6 +27,7 @@ struct OsdArgs {
 
 __global__ void __launch_bounds__(256) osd0_kernel(GraphDev g, OsdArgs a)
 {
+    FG_LOG_TAB_SETUP();
     extern __shared__ unsigned char smem[];
     const int tid = threadIdx.x, T = 256;
     const int n = g.n, rank = a.rank, W = a.W, WS = a.WS;
@@ -193,7 +194,7 @@ extern "C" int fgnn_osd0(const fgnn_graph* g, int side, const float* marg, const
     a.e_hat = e_hat;
     const size_t lds = sizeof(unsigned long long) * (size_t)a.NP + sizeof(unsigned) * (size_t)a.rank * a.WS +
                        sizeof(int) * (size_t)(2 * g->d.n + a.rank);
-    if (lds > 160 * 1024) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident OSD kernel");
+    if (lds > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident OSD kernel");
     if (lds > 48 * 1024)
         FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(osd0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(osd0_kernel, dim3(count), dim3(256), lds, static_cast<hipStream_t>(stream), g->d, a);

@@ -72,6 +72,7 @@ def test_gpu_vs_numpy_restatement(name, p, iters):
     o = _np(g.bp4_decode(sx, sz, iters, "boxplus-phi", 1.0, llr_const=L0))
     r = R.bp4_decode(R.Graph(c), nsx, nsz, iters, llr_const=L0)
     hx, hz = np.asarray(c.hx), np.asarray(c.hz)
+    CODE = c
 
     def converged(d):
         return ~(((d["x_hat"].astype(int) @ hz.T % 2) != nsz).any(1) | ((d["z_hat"].astype(int) @ hx.T % 2) != nsx).any(1))
@@ -81,7 +82,14 @@ def test_gpu_vs_numpy_restatement(name, p, iters):
     same = (o["x_hat"] == r["x_hat"]).all(1) & (o["z_hat"] == r["z_hat"]).all(1)
     assert both.sum() >= B // 4, "too few converged samples for the comparison to mean anything"
     assert flipped.mean() <= 0.15 and abs(converged(o).mean() - converged(r).mean()) <= 0.06
-    assert same[both].mean() >= 0.98, "decisions differ on samples both implementations converge on"
+    # [[n,k]] stabilizer codes are degenerate: two estimates that differ by a stabilizer (a sum of check rows) are the SAME
+    # correction.  Chaotic transients occasionally end on different representatives (weight-6 check rows, observed), so the
+    # bar is: every commonly converged sample gets the same correction class — d_x in rowspace(hx) <=> hx_perp . d_x = 0,
+    # likewise z — and all but a few get the identical representative.
+    HXP, HZP = np.asarray(CODE.hx_perp).astype(int), np.asarray(CODE.hz_perp).astype(int)
+    equiv = ~(((o["x_hat"] ^ r["x_hat"]).astype(int) @ HXP.T % 2).any(1) | ((o["z_hat"] ^ r["z_hat"]).astype(int) @ HZP.T % 2).any(1))
+    assert equiv[both].mean() >= 0.98, "different correction classes on samples both implementations converge on"
+    assert same[both].mean() >= 0.95, "too many different representatives on samples both implementations converge on"
     d = np.abs(o["llr"] - r["llr"]).reshape(B, -1).max(1)
     dl = np.abs(o["x_logit"] - r["x_logit"]).reshape(B, -1).max(1)
     if c.N >= 800:
