@@ -310,7 +310,28 @@ def main():
             g.set_saturation_shortcut(True)
             t_cs = timed(lambda: model_c.mc_step(B, args.p, cc))
             g.set_saturation_shortcut(False)
+            # OPT-IN variant, never the headline: the phi rule on v_exp_f32 / v_log_f32 (FGNN_OPT_HW_TRANSCENDENTALS), and how
+            # far its results are from the exact kernel's on this very batch — the measured price of bit-exactness
+            exact = g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0)
+            g.set_hw_transcendentals(True)
+            t_hw = timed(lambda: g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0))
+            hw = g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0)
+            g.set_hw_transcendentals(False)
+            same_dec = ((exact["x_hat"] == hw["x_hat"]).all(1) & (exact["z_hat"] == hw["z_hat"]).all(1))
+            ones = torch.ones(B, dtype=torch.uint8, device="cuda")
+            conv_e = g.flag_update(exact["x_hat"], exact["z_hat"], sx, sz, ones.clone()) == 0
+            conv_h = g.flag_update(hw["x_hat"], hw["z_hat"], sx, sz, ones.clone()) == 0
+            both = conv_e & conv_h
+            dl = (exact["llr"] - hw["llr"]).abs().flatten(1).max(1).values
+            nb = max(int(both.sum()), 1)
+            hw_info = {"cw_per_s": B / t_hw, "speedup_vs_exact_kernel": t_bp / t_hw,
+                       "samples": B, "converged_exact": int(conv_e.sum()), "converged_hw": int(conv_h.sum()),
+                       "identical_decisions_all_samples": float(same_dec.float().mean()),
+                       "identical_decisions_on_samples_both_converge": float(same_dec[both].float().mean()) if int(both.sum()) else None,
+                       "max_abs_llr_diff_le_1e-4_on_samples_both_converge": float((dl[both] <= 1e-4).sum()) / nb,
+                       "median_abs_llr_diff_on_samples_both_converge": float(dl[both].median()) if int(both.sum()) else None}
             out["extras"] = {"bp4_only_cw_per_s (configs[1])": B / t_bp,
+                             "bp4_only_HW_TRANSCENDENTALS_opt_in_NOT_bit_exact (v_exp_f32/v_log_f32, fixed dataflow)": hw_info,
                              "bp4_only_product_default_cw_per_s (exact saturation shortcut + fixed-point exit, identical outputs)": B / t_bp_s,
                              "sandwich_product_default_cw_per_s (exact saturation shortcut + fixed-point exit, identical outputs)": B / t_s,
                              "sandwich_compacted_cw_per_s (feedback rounds only on flagged samples, same outputs)": B / t_c,

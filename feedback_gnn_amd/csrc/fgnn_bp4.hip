@@ -21,6 +21,13 @@
 #include "fgnn_internal.h"
 #include "fgnn_math.h"
 
+#ifndef FGNN_BP4_WAVES
+#define FGNN_BP4_WAVES 7  // waves per SIMD the register allocator must leave room for (LDS admits 5-7 workgroups of 4 waves per CU)
+#endif
+#ifndef FGNN_PHI_STAGE
+#define FGNN_PHI_STAGE 1  // phi evaluations staged together in the regular check-node update (phi_n), must divide DC
+#endif
+
 namespace {
 
 struct BpArgs {
@@ -42,6 +49,7 @@ struct BpArgs {
     int shortcut;             // 1: wave-uniform exact shortcuts for saturated nodes (regular kernel)
     int early_exit;           // 1: leave the iteration loop at a proven fixed point (needs shortcut, cpb == 1, phi rule)
     int sig_off;              // float offset of the fixed-point detector's LDS words (n sign words + 4 flags)
+    int hwt;                  // 1: v_exp_f32 / v_log_f32 instead of fgnn_math.h (FGNN_OPT_HW_TRANSCENDENTALS; phi rule, fixed dataflow)
     uint8_t* flagged;         // optional [B]: 1 iff the decision's syndrome differs from the measured one (feedback_gnn.py:324-328)
     int flag_off;             // float offset of n decision bytes + one word in LDS (only when flagged != null)
 };
@@ -49,12 +57,47 @@ struct BpArgs {
 __device__ __forceinline__ unsigned sign_bit(float x) { return fg_f2u(x) >> 31; }
 __device__ __forceinline__ float with_sign(float mag, unsigned neg) { return fg_u2f(fg_f2u(mag) ^ (neg << 31)); }
 
+// Elementary-function policy of the kernel.  Mx<false> = fgnn_math.h: the float operations the CPU oracle executes, bit for bit
+// (the default, the headline, every parity test).  Mx<true> = the same TensorFlow op structure on the hardware's own
+// v_exp_f32 / v_log_f32 (1-ulp table units whose bits no CPU reproduces): FGNN_OPT_HW_TRANSCENDENTALS, explicitly opt-in, fixed
+// dataflow only, reported by bench.py under `extras` next to its measured agreement with the exact kernel — the price of
+// bit-exactness as a number.  What a TensorFlow-ROCm build of the reference would execute is of this kind.
+template <bool HWT>
+struct Mx {
+    static __device__ __forceinline__ float softplus(float t) { return fg_softplus(t); }
+    static __device__ __forceinline__ float lse2(float a, float b) { return fg_lse2(a, b); }
+    static __device__ __forceinline__ float phi(float x) { return fg_phi(x); }
+};
+template <>
+struct Mx<true> {
+    static __device__ __forceinline__ float exp(float x) { return __builtin_amdgcn_exp2f(x * FG_LOG2E); }
+    static __device__ __forceinline__ float log(float x) { return __builtin_amdgcn_logf(x) * 0.693147182f; }
+    static __device__ __forceinline__ float softplus(float t)  // tf2xla Softplus, as fg_softplus
+    {
+        const float y = exp(FG_CLAMP(t, -87.0f, FG_SOFTPLUS_THRESH));
+        const float r = (t < -FG_SOFTPLUS_THRESH) ? ((t < -87.0f) ? 0.0f : y) : log(1.0f + y);
+        return (t > FG_SOFTPLUS_THRESH) ? t : r;
+    }
+    static __device__ __forceinline__ float lse2(float a, float b)  // max-shifted reduce_logsumexp of a pair, as fg_lse2
+    {
+        const float y = exp(-FG_MIN(FG_ABS(a - b), 20.0f));
+        return log(1.0f + y) + FG_MAX(a, b);
+    }
+    static __device__ __forceinline__ float phi(float x)  // decoding_q.py:365-373, as fg_phi
+    {
+        const float xc = FG_CLAMP(x, FG_PHI_MIN, FG_PHI_MAX);
+        const float y = exp(xc);
+        const float sp = (xc > FG_SOFTPLUS_THRESH) ? xc : log(1.0f + y);
+        return sp - log(y - 1.0f);
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Check-node rules on runtime-degree rows.  `msg` = this codeword's LDS message array, `slot` =
 // the check's slot list.  Pass 1 parks |.|-type intermediates in the slots themselves (sign kept in
 // the sign bit), pass 2 writes the c->v messages.  decoding_q.py line numbers as in the oracle.
 // ---------------------------------------------------------------------------------------------
-template <int CN_TYPE>
+template <int CN_TYPE, bool HWT = false>
 __device__ __forceinline__ void cn_update(float* msg, const int* __restrict__ slot, int deg, unsigned synd, float factor)
 {
     if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI) {  // _cn_update_phi (:376-431)
@@ -65,14 +108,14 @@ __device__ __forceinline__ void cn_update(float* msg, const int* __restrict__ sl
             float v = msg[s];
             unsigned ng = v < 0.0f;
             neg ^= ng;
-            float a = fg_phi(FG_ABS(v));
+            float a = Mx<HWT>::phi(FG_ABS(v));
             T = T + a;
             msg[s] = with_sign(a, ng);
         }
         for (int j = 0; j < deg; ++j) {
             int s = slot[j];
             float w = msg[s];
-            float out = fg_phi(T - FG_ABS(w));
+            float out = Mx<HWT>::phi(T - FG_ABS(w));
             msg[s] = with_sign(out, neg ^ sign_bit(w)) * factor;
         }
     } else if constexpr (CN_TYPE == FGNN_CN_MINSUM) {  // _cn_update_minsum (:539-644)
@@ -129,6 +172,7 @@ __device__ __forceinline__ void cn_update(float* msg, const int* __restrict__ sl
 }
 
 // soft syndrome of one row, _cn_update_phi_loss (:433-453)
+template <bool HWT = false>
 __device__ __forceinline__ float logit_row(const float* llr, const int* __restrict__ col, int deg)
 {
     unsigned neg = 0;
@@ -136,13 +180,14 @@ __device__ __forceinline__ float logit_row(const float* llr, const int* __restri
     for (int j = 0; j < deg; ++j) {
         float v = llr[col[j]];
         neg ^= (v < 0.0f);
-        T = T + fg_phi(FG_ABS(v));
+        T = T + Mx<HWT>::phi(FG_ABS(v));
     }
-    return with_sign(fg_phi(T), neg);
+    return with_sign(Mx<HWT>::phi(T), neg);
 }
 
 // The same with the exact saturation shortcut: a wave whose rows all see |llr| >= 16.635532 everywhere has phi(|.|) = 0 for every
 // term, T = 0 and phi(T) = phi(clip min) = phi0 — the soft syndrome of a converged codeword.
+template <bool HWT = false>
 __device__ __forceinline__ float logit_row_opt(const float* llr, const int* __restrict__ col, int deg, float phi0, bool shortcut)
 {
     if (shortcut) {
@@ -155,24 +200,75 @@ __device__ __forceinline__ float logit_row_opt(const float* llr, const int* __re
         }
         if (__all(sat)) return with_sign(phi0, neg);
     }
-    return logit_row(llr, col, deg);
+    return logit_row<HWT>(llr, col, deg);
+}
+
+// N evaluations of fg_phi (fgnn_math.h) with the work of the N lanes-worth of values laid out in three stages, so that the 2N table
+// reads of the logs are in flight together instead of one read - wait - use per log: (A) clamp, exp, the two log arguments and
+// their table addresses; (B) the 2N two-dword LDS reads; (C) remainders, polynomials, assembly.  Every value goes through exactly
+// the float operations of fg_phi in the same order — only the instruction schedule differs, the bits do not.
+template <int N, bool HWT = false>
+__device__ __forceinline__ void phi_n(const float (&x)[N], float (&out)[N])
+{
+    if constexpr (HWT) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) out[k] = Mx<true>::phi(x[k]);
+        return;
+    }
+    const float* tab = fg_log_tab();
+    float xc[N], y[N];
+    uint32_t eb1[N], eb2[N], j1[N], j2[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        xc[k] = FG_CLAMP(x[k], FG_PHI_MIN, FG_PHI_MAX);
+        y[k] = fg_exp(xc[k]);
+        const uint32_t w1 = fg_f2u(1.0f + y[k]) - FG_LOG_OFFS;  // fg_log1p(y)
+        const uint32_t w2 = fg_f2u(y[k] - 1.0f) - FG_LOG_OFFS;  // fg_log(y - 1)
+        eb1[k] = w1 & 0xff800000u;
+        eb2[k] = w2 & 0xff800000u;
+        j1[k] = (w1 >> 18) & 31u;
+        j2[k] = (w2 >> 18) & 31u;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float rc1[N], lc1[N], rc2[N], lc2[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        rc1[k] = tab[j1[k]];
+        lc1[k] = tab[32 + j1[k]];
+        rc2[k] = tab[j2[k]];
+        lc2[k] = tab[32 + j2[k]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float a = fg_u2f(fg_f2u(rc1[k]) - eb1[k]);
+        const float r1 = FG_FMA(y[k], a, a - 1.0f);
+        float sp = FG_FMA((float)(int32_t)eb1[k], FG_LN2_S23, lc1[k] + fg_log1p_small(r1));
+        sp = (xc[k] > FG_SOFTPLUS_THRESH) ? xc[k] : sp;
+        const float mm = fg_u2f(fg_f2u(y[k] - 1.0f) - eb2[k]);
+        const float r2 = FG_FMA(mm, rc2[k], -1.0f);
+        const float lg = FG_FMA((float)(int32_t)eb2[k], FG_LN2_S23, lc2[k] + fg_log1p_small(r2));
+        out[k] = sp - lg;
+    }
 }
 
 // c->v update of one (DC-regular) check with every message in registers: the phi rule of the benchmark
 // configurations without the LDS round trip of the runtime-degree version.  Same float ops, same order.
-template <int DC>
+// Signs are carried as integer sign words: neg = (synd << 31) ^ bits(v_0) ^ ... (bit 31 = the parity of :398-399), and the
+// outgoing sign of edge j is bit 31 of neg ^ bits(v_j) — one xor per edge in, one xor + one bit-field insert per edge out.
+template <int DC, bool HWT = false>
 __device__ __forceinline__ bool cn_phi_regular(float* msg, const int (&sl)[DC], unsigned synd, float factor, float phi0,
                                                bool shortcut)
 {
+    constexpr int H = (DC % FGNN_PHI_STAGE == 0) ? FGNN_PHI_STAGE : DC / 2;
+    static_assert(DC % H == 0, "a phi stage must take a whole fraction of a check");
     float v[DC], aa[DC];
-    unsigned ng[DC];
-    unsigned neg = synd;
+    uint32_t neg = synd << 31;
     bool sat = true;
 #pragma unroll
     for (int j = 0; j < DC; ++j) {
         v[j] = msg[sl[j]];
-        ng[j] = v[j] < 0.0f;
-        neg ^= ng[j];
+        neg ^= fg_f2u(v[j]);
         sat = sat && (FG_ABS(v[j]) >= FG_PHI_MAX);
     }
     // Saturation shortcut (exact): if every incoming |nu| >= 16.635532 then every phi(|nu|) is phi(clip max) = 0
@@ -180,24 +276,36 @@ __device__ __forceinline__ bool cn_phi_regular(float* msg, const int (&sl)[DC], 
     // lanes of the wave are saturated (one v_cmp + s_cbranch), which is the steady state of a converged codeword.
     if (shortcut && __all(sat)) {
 #pragma unroll
-        for (int j = 0; j < DC; ++j) msg[sl[j]] = with_sign(phi0, neg ^ ng[j]) * factor;
+        for (int j = 0; j < DC; ++j) msg[sl[j]] = fg_u2f(fg_f2u(phi0) | ((neg ^ fg_f2u(v[j])) & 0x80000000u)) * factor;
         return true;
+    }
+#pragma unroll
+    for (int g0 = 0; g0 < DC; g0 += H) {
+        float xa[H], oa[H];
+#pragma unroll
+        for (int j = 0; j < H; ++j) xa[j] = FG_ABS(v[g0 + j]);
+        phi_n<H, HWT>(xa, oa);
+#pragma unroll
+        for (int j = 0; j < H; ++j) aa[g0 + j] = oa[j];
     }
     float T = 0.0f;
 #pragma unroll
-    for (int j = 0; j < DC; ++j) {
-        aa[j] = fg_phi(FG_ABS(v[j]));
-        T = T + aa[j];
-    }
+    for (int j = 0; j < DC; ++j) T = T + aa[j];
 #pragma unroll
-    for (int j = 0; j < DC; ++j) {
-        const float out = fg_phi(T - aa[j]);
-        msg[sl[j]] = with_sign(out, neg ^ ng[j]) * factor;
+    for (int g0 = 0; g0 < DC; g0 += H) {
+        float xa[H], oa[H];
+#pragma unroll
+        for (int j = 0; j < H; ++j) xa[j] = T - aa[g0 + j];
+        phi_n<H, HWT>(xa, oa);
+#pragma unroll
+        for (int j = 0; j < H; ++j)
+            msg[sl[g0 + j]] = fg_u2f(fg_f2u(oa[j]) | ((neg ^ fg_f2u(v[g0 + j])) & 0x80000000u)) * factor;
     }
     return false;
 }
 
 // Runtime-degree phi rule with the exact saturation shortcut of cn_phi_regular: returns true when the whole wave took it.
+template <bool HWT = false>
 __device__ __forceinline__ bool cn_phi_generic(float* msg, const int* __restrict__ slot, int deg, unsigned synd, float factor,
                                                float phi0, bool shortcut)
 {
@@ -217,7 +325,7 @@ __device__ __forceinline__ bool cn_phi_generic(float* msg, const int* __restrict
             return true;
         }
     }
-    cn_update<FGNN_CN_BOXPLUS_PHI>(msg, slot, deg, synd, factor);
+    cn_update<FGNN_CN_BOXPLUS_PHI, HWT>(msg, slot, deg, synd, factor);
     return false;
 }
 
@@ -233,9 +341,11 @@ __device__ __forceinline__ float softplus_saturated(float t)
 // 16-byte row of g.cslot16.  DVX = 0: runtime degrees through the CSR tables.
 // OPT = false compiles the exact optimisations (saturation shortcut, fixed-point detector) out: the fixed-dataflow
 // variant bench.py's headline times carries none of their tests.
-template <int CN_TYPE, int DVX, int DVZ, int DC, bool OPT>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) bp4_kernel(GraphDev g, BpArgs a)
+template <int CN_TYPE, int DVX, int DVZ, int DC, bool OPT, bool HWT = false>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FGNN_BP4_WAVES))) bp4_kernel(GraphDev g, BpArgs a)
 {
+    static_assert(!(HWT && OPT), "the hardware-transcendental variant is the fixed dataflow only: the exact shortcuts are proofs about fgnn_math.h");
+    using MX = Mx<HWT>;
     FG_LOG_TAB_SETUP();
     constexpr bool REGULAR = DVX > 0;
     const bool opt_shortcut = OPT && a.shortcut != 0;
@@ -267,7 +377,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) 
     const uint8_t* sz = a.synd_z + (size_t)b * g.m_z;
     const int lane_c = lane + (a.tpc >> 1) < a.tpc ? lane + (a.tpc >> 1) : lane - a.tpc + (a.tpc >> 1);
 
-    const float phi0 = fg_phi(0.0f);  // = phi(clip min) = 16.6355324, the saturated message magnitude
+    const float phi0 = MX::phi(0.0f);  // = phi(clip min) = 16.6355324, the saturated message magnitude
     (void)phi0;
     // Fixed-point detector (exact early exit, regular phi kernel, one codeword per block).  If the check-node phases of
     // iterations t-1 and t-2 were all-shortcut, every c->v message entering iterations t-1 and t has the same magnitude
@@ -289,8 +399,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) 
             // (:244-248), v->c (:254-273), then the phi rule on six equal inputs (:376-431) in the summation order of cn_phi_regular
             const float L = a.llr_const;
             const float Y = (0.0f + 0.0f) + L, X = 0.0f + L, Z = 0.0f + L;
-            const float nu_x = fg_softplus(-X) - fg_lse2(-(Z - 0.0f), -(Y - 0.0f));
-            const float nu_z = fg_softplus(-Z) - fg_lse2(-(X - 0.0f), -(Y - 0.0f));
+            const float nu_x = MX::softplus(-X) - MX::lse2(-(Z - 0.0f), -(Y - 0.0f));
+            const float nu_z = MX::softplus(-Z) - MX::lse2(-(X - 0.0f), -(Y - 0.0f));
             if (active)
                 for (int c = lane_c; c < g.m; c += a.tpc) {
                     const unsigned synd = (c < g.m_x ? sx[c] : sz[c - g.m_x]) & 1u;
@@ -299,14 +409,14 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) 
                     const float nu = c < g.m_x ? nu_x : nu_z;
                     const unsigned ng = nu < 0.0f;
                     unsigned neg = synd;
-                    const float aa = fg_phi(FG_ABS(nu));
+                    const float aa = MX::phi(FG_ABS(nu));
                     float T = 0.0f;
 #pragma unroll
                     for (int j = 0; j < DC; ++j) {
                         neg ^= ng;
                         T = T + aa;
                     }
-                    const float val = with_sign(fg_phi(T - aa), neg ^ ng) * a.factor;
+                    const float val = with_sign(MX::phi(T - aa), neg ^ ng) * a.factor;
 #pragma unroll
                     for (int j = 0; j < DC; ++j) msg[(int)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu)] = val;
                 }
@@ -368,17 +478,17 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) 
                         }
                         continue;
                     }
-                    const float numx = fg_softplus(-X);
-                    const float numz = fg_softplus(-Z);
+                    const float numx = MX::softplus(-X);
+                    const float numz = MX::softplus(-Z);
 #pragma unroll
                     for (int k = 0; k < DVX; ++k) {
                         const float Ze = Z - mx[k], Ye = Y - mx[k];
-                        px[k] = numx - fg_lse2(-Ze, -Ye);
+                        px[k] = numx - MX::lse2(-Ze, -Ye);
                     }
 #pragma unroll
                     for (int k = 0; k < DVZ; ++k) {
                         const float Xe = X - mz[k], Ye = Y - mz[k];
-                        pz[k] = numz - fg_lse2(-Xe, -Ye);
+                        pz[k] = numz - MX::lse2(-Xe, -Ye);
                     }
                 } else {
                     const int x0 = g.vptr_x[v], x1 = g.vptr_x[v + 1], z0 = g.vptr_z[v], z1 = g.vptr_z[v + 1];
@@ -420,17 +530,17 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) 
                             continue;
                         }
                     }
-                    const float numx = fg_softplus(-X);
-                    const float numz = fg_softplus(-Z);
+                    const float numx = MX::softplus(-X);
+                    const float numz = MX::softplus(-Z);
                     for (int e = x0; e < x1; ++e) {
                         float m = msg[e];
                         float Ze = Z - m, Ye = Y - m;
-                        msg[e] = numx - fg_lse2(-Ze, -Ye);
+                        msg[e] = numx - MX::lse2(-Ze, -Ye);
                     }
                     for (int e = z0; e < z1; ++e) {
                         float m = msg[e];
                         float Xe = X - m, Ye = Y - m;
-                        msg[e] = numz - fg_lse2(-Xe, -Ye);
+                        msg[e] = numz - MX::lse2(-Xe, -Ye);
                     }
                 }
             }
@@ -453,13 +563,13 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) 
 #pragma unroll
                     for (int j = 0; j < DC; ++j) sl[j] = (int)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
                     if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI)
-                        cn_slow = !cn_phi_regular<DC>(msg, sl, synd, a.factor, phi0, opt_shortcut) || cn_slow;
-                    else cn_update<CN_TYPE>(msg, sl, DC, synd, a.factor);
+                        cn_slow = !cn_phi_regular<DC, HWT>(msg, sl, synd, a.factor, phi0, opt_shortcut) || cn_slow;
+                    else cn_update<CN_TYPE, HWT>(msg, sl, DC, synd, a.factor);
                 } else {
                     const int c0 = g.cptr[c], deg = g.cptr[c + 1] - c0;
                     if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI)
-                        cn_slow = !cn_phi_generic(msg, g.cslot + c0, deg, synd, a.factor, phi0, opt_shortcut) || cn_slow;
-                    else cn_update<CN_TYPE>(msg, g.cslot + c0, deg, synd, a.factor);
+                        cn_slow = !cn_phi_generic<HWT>(msg, g.cslot + c0, deg, synd, a.factor, phi0, opt_shortcut) || cn_slow;
+                    else cn_update<CN_TYPE, HWT>(msg, g.cslot + c0, deg, synd, a.factor);
                 }
             }
         if (opt_exit && cn_slow) flags[2 * (it & 1) + 1] = 1;
@@ -541,20 +651,20 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7))) 
                 llx[v] = softplus_saturated(-Z) - (0.0f + FG_MAX(-X, -Y));
                 continue;
             }
-            llz[v] = fg_softplus(-X) - fg_lse2(-Z, -Y);
-            llx[v] = fg_softplus(-Z) - fg_lse2(-X, -Y);
+            llz[v] = MX::softplus(-X) - MX::lse2(-Z, -Y);
+            llx[v] = MX::softplus(-Z) - MX::lse2(-X, -Y);
         }
     __syncthreads();
     if (active) {
         if (a.x_logit)
             for (int r = lane; r < g.rows[0]; r += a.tpc) {
                 const int p0 = g.rptr[0][r];
-                a.x_logit[(size_t)b * g.rows[0] + r] = logit_row_opt(llx, g.rcol[0] + p0, g.rptr[0][r + 1] - p0, phi0, opt_shortcut);
+                a.x_logit[(size_t)b * g.rows[0] + r] = logit_row_opt<HWT>(llx, g.rcol[0] + p0, g.rptr[0][r + 1] - p0, phi0, opt_shortcut);
             }
         if (a.z_logit)
             for (int r = lane; r < g.rows[1]; r += a.tpc) {
                 const int p0 = g.rptr[1][r];
-                a.z_logit[(size_t)b * g.rows[1] + r] = logit_row_opt(llz, g.rcol[1] + p0, g.rptr[1][r + 1] - p0, phi0, opt_shortcut);
+                a.z_logit[(size_t)b * g.rows[1] + r] = logit_row_opt<HWT>(llz, g.rcol[1] + p0, g.rptr[1][r + 1] - p0, phi0, opt_shortcut);
             }
     }
 }
@@ -563,6 +673,9 @@ template <int CN_TYPE, int DVX, int DVZ, int DC>
 int launch_bp4_k(const fgnn_graph* g, const BpArgs& a, const LaunchGeom& L, size_t lds_bytes, hipStream_t st)
 {
     auto kern = a.shortcut ? bp4_kernel<CN_TYPE, DVX, DVZ, DC, true> : bp4_kernel<CN_TYPE, DVX, DVZ, DC, false>;
+    if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI) {
+        if (a.hwt) kern = bp4_kernel<CN_TYPE, DVX, DVZ, DC, false, true>;  // opt-in, fixed dataflow (fgnn_graph_set_option 3)
+    }
     if (lds_bytes > 48 * 1024)
         FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes));
@@ -618,7 +731,8 @@ int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float n
     a.msg_out_x = msg_out_x;
     a.msg_out_z = msg_out_z;
     a.index = index;
-    a.shortcut = g->shortcut ? 1 : 0;
+    a.hwt = (g->hw_transcendentals && cn_type == FGNN_CN_BOXPLUS_PHI) ? 1 : 0;
+    a.shortcut = (g->shortcut && !a.hwt) ? 1 : 0;
     // floats per codeword: messages (>= 2n so the epilogue's binary LLRs fit) + channel LLRs
     a.lch_off = g->d.E > 2 * g->d.n ? g->d.E : 2 * g->d.n;
     int per_cw = a.lch_off + (llr_ch ? 3 * g->d.n : 0);
@@ -628,7 +742,7 @@ int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float n
     const bool regular = g->d.cslot16 && !g->force_generic &&
                          ((g->d.dvx == 3 && g->d.dvz == 3 && g->d.dc == 6) || (g->d.dvx == 4 && g->d.dvz == 4 && g->d.dc == 8));
     (void)regular;
-    a.early_exit = (g->shortcut && g->early_exit && g->d.max_vdeg <= 32 && cn_type == FGNN_CN_BOXPLUS_PHI && L.cpb == 1 &&
+    a.early_exit = (a.shortcut && g->early_exit && g->d.max_vdeg <= 32 && cn_type == FGNN_CN_BOXPLUS_PHI && L.cpb == 1 &&
                     num_iter > 2) ? 1 : 0;
     a.sig_off = per_cw;
     if (a.early_exit) {

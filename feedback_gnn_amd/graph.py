@@ -155,6 +155,11 @@ class TannerGraph:
         """Exact early exit of converged codewords (FGNN_OPT_FIXED_POINT_EXIT; only acts with the saturation shortcut on)."""
         check(_lib.lib().fgnn_graph_set_option(self.handle, 2, int(bool(on))))
 
+    def set_hw_transcendentals(self, on=True):
+        """OPT-IN, not bit-exact (FGNN_OPT_HW_TRANSCENDENTALS): boxplus-phi decodes run on v_exp_f32 / v_log_f32 in the fixed
+        dataflow.  Off by default; no parity test and no headline number uses it."""
+        check(_lib.lib().fgnn_graph_set_option(self.handle, 3, int(bool(on))))
+
     def force_generic(self, on=True):
         """Testing hook: run the runtime-degree kernel even on a degree-regular graph."""
         check(_lib.lib().fgnn_graph_force_generic(self.handle, int(bool(on))))

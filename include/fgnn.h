@@ -74,8 +74,14 @@ int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords
  * at most 32 edges per qubit):
  * when two consecutive check-node phases were all-saturated and no c->v sign changed in between, the messages are at a
  * bit-exact fixed point of the (deterministic) iteration map, every remaining iteration is the identity, and the
- * workgroup leaves the loop.  Results are identical with 0 and 1. */
-enum { FGNN_OPT_SATURATION_SHORTCUT = 1, FGNN_OPT_FIXED_POINT_EXIT = 2 };
+ * workgroup leaves the loop.  Results are identical with 0 and 1.
+ * FGNN_OPT_HW_TRANSCENDENTALS (default 0; opt-in, NOT bit-exact, never used by a parity test or by bench.py's headline):
+ * boxplus-phi decodes evaluate exp / log on the hardware's v_exp_f32 / v_log_f32 units instead of the shared float32 routines
+ * of fgnn_math.h, in the fixed dataflow (the two exact options above are proofs about fgnn_math.h and are ignored while this is
+ * set).  Same TensorFlow op structure (softplus thresholds, max-shifted log-sum-exp, _phi clip), ~1 ulp per elementary function,
+ * but bits that no CPU oracle reproduces: on non-converged samples decisions may differ from the default path's (chaotic
+ * transients).  bench.py reports its rate and its measured agreement with the exact kernel under `extras`. */
+enum { FGNN_OPT_SATURATION_SHORTCUT = 1, FGNN_OPT_FIXED_POINT_EXIT = 2, FGNN_OPT_HW_TRANSCENDENTALS = 3 };
 int fgnn_graph_set_option(fgnn_graph* g, int option, int value);
 /* Testing hook: on != 0 forces the runtime-degree (CSR) kernel even on a degree-regular graph. */
 int fgnn_graph_force_generic(fgnn_graph* g, int on);
