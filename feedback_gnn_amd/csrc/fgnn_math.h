@@ -7,7 +7,7 @@
  *   - by gcc    (-ffp-contract=off -mfma) into the CPU oracle (the .c files under oracle),
  * so a GPU result and an oracle result are the same bits, for every sample and every iteration.
  * Accuracy (tools/check_math.c, exhaustive over the domains used): exp <= 0.9 ulp,
- * log <= 1.2 ulp, log1p <= 1.3 ulp, tanh <= 2.7 ulp — the same class as TensorFlow's own Eigen / XLA kernels,
+ * log <= 1.2 ulp, log1p <= 1.3 ulp, tanh <= 3.8 ulp (5.8 where it saturates) — the same class as TensorFlow's own Eigen / XLA kernels,
  * which are not correctly rounded either (SURVEY.md §8c "Third-party arithmetic").
  *
  * The composite functions restate TensorFlow op semantics used by the reference:
@@ -223,16 +223,23 @@ FG_FN float fg_div3(float x)
 }
 
 /* ---- tanh / atanh (feedback-GNN activations, 'boxplus' check-node rule) ------------------ */
-/* a / b for b = a + 2, a in [0, 2^58] (the quotient of fg_tanh).  The CPU divides.  The device refines v_rcp_f32 with exact
- * remainders; the result is the correctly rounded quotient — the CPU's — for every float in that range, which
- * tests/div_exhaustive.hip checks one by one on the GPU (tests/test_math.py).  About half the slots of the general division
- * sequence (no v_div_scale / v_div_fixup: nothing here needs rescaling). */
-FG_FN float fg_div_em1(float a, float b)
+/* tanh(x) = x * P(x^2) / Q(x^2) on |x| <= 9 (beyond it tanh rounds to +-1), P and Q of degree 4 in x^2 with P(0) = Q(0) = 1, so
+ * small arguments keep full relative accuracy (tanh x -> x exactly).  This is the form XLA itself compiles tf.tanh to inside a
+ * jit-compiled function (clamp, odd rational, one division), which is how the reference runs its MLPs (feedback_gnn.py:293
+ * @tf.function(jit_compile=True)).  Minimax fit: tools/fit_tanh.py (0.36 ulp in exact arithmetic); evaluated in float32: <= 3.8 ulp
+ * for |x| <= 2, <= 5.8 ulp where tanh is within 1e-3 of +-1 (tools/check_math.c, exhaustive).  16 VALU slots on gfx950 (the expm1
+ * form it replaces: 24).
+ *
+ * The quotient a / b: the CPU divides.  The device refines v_rcp_f32 with exact remainders; the result is the correctly rounded
+ * quotient — the CPU's — for every (a, b) fg_tanh can form, which tests/div_exhaustive.hip checks one float x at a time on the GPU
+ * (tests/test_math.py).  About half the slots of the general division sequence (no v_div_scale / v_div_fixup: b is in [1, 200]). */
+#define FG_TANH_MAX 9.0f
+FG_FN float fg_div_tanh(float a, float b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     const float r = __builtin_amdgcn_rcpf(b);
     float q = a * r;
-    float e = FG_FMA(-b, q, a);
+    const float e = FG_FMA(-b, q, a);
     q = FG_FMA(e, r, q);
     return q;
 #else
@@ -240,25 +247,31 @@ FG_FN float fg_div_em1(float a, float b)
 #endif
 }
 
+/* numerator x*P(x^2) and denominator Q(x^2) of fg_tanh for ax = min(|x|, 9) (separate so that the exhaustive division check walks
+ * exactly the pairs the function forms) */
+FG_FN void fg_tanh_parts(float ax, float* num, float* den)
+{
+    const float z = ax * ax;
+    float pp = 1.341787081e-08f;
+    pp = FG_FMA(pp, z, 2.065990651e-05f);
+    pp = FG_FMA(pp, z, 3.498917000e-03f);
+    pp = FG_FMA(pp, z, 1.338391516e-01f);
+    pp = FG_FMA(pp, z, 1.0f);
+    float qq = 7.803944492e-07f;
+    qq = FG_FMA(qq, z, 3.290906479e-04f);
+    qq = FG_FMA(qq, z, 2.588990991e-02f);
+    qq = FG_FMA(qq, z, 4.671723671e-01f);
+    qq = FG_FMA(qq, z, 1.0f);
+    *num = ax * pp;
+    *den = qq;
+}
+
 FG_FN float fg_tanh(float x)
 {
-    /* tanh|x| = em1/(em1+2), em1 = expm1(2|x|) = 2^k*(e^r - 1) + (2^k - 1) with the reduction and the
-     * polynomial of fg_exp.  For k = 0 this is r + r^2*q(r) with r = 2|x| exactly, so small arguments keep
-     * full relative accuracy without a second branch. */
-    float t = FG_MIN(FG_ABS(x) + FG_ABS(x), 40.0f);
-    float tt = FG_FMA(t, FG_LOG2E, FG_RND_MAGIC);
-    float k = tt - FG_RND_MAGIC;
-    float r = FG_FMA(k, -FG_LN2_HI, t);
-    r = FG_FMA(k, -FG_LN2_LO, r);
-    float q = 1.381461043e-03f;
-    q = FG_FMA(q, r, 8.368710056e-03f);
-    q = FG_FMA(q, r, 4.166838899e-02f);
-    q = FG_FMA(q, r, 1.666652113e-01f);
-    q = FG_FMA(q, r, 4.999999404e-01f);
-    float pm1 = FG_FMA(r * r, q, r);                         /* e^r - 1 */
-    float sc = fg_u2f((fg_f2u(tt) << 23) + 0x3f800000u);     /* 2^k, k in [0, 58] */
-    float em1 = FG_FMA(sc, pm1, sc - 1.0f);
-    float y = fg_div_em1(em1, em1 + 2.0f);
+    const float ax = FG_MIN(FG_ABS(x), FG_TANH_MAX);
+    float num, den;
+    fg_tanh_parts(ax, &num, &den);
+    const float y = fg_div_tanh(num, den);
     return fg_u2f(fg_f2u(y) | (fg_f2u(x) & 0x80000000u));
 }
 

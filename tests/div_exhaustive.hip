@@ -1,9 +1,11 @@
-// tests/div_exhaustive.hip — exhaustive proof obligations of fg_div_em1 and fg_div3 (feedback_gnn_amd/csrc/fgnn_math.h) on the target GPU.
+// tests/div_exhaustive.hip — exhaustive proof obligations of the device division sequences of feedback_gnn_amd/csrc/fgnn_math.h
+// (fg_div_tanh, fg_div3, fg_div_atanh, fg_rcp_unit) on the target GPU.
 //
-// fg_tanh needs em1 / (em1 + 2) for em1 in [0, e^40].  On the device that quotient is formed from v_rcp_f32 and fma refinement steps
-// (about half the instruction slots of the compiler's general IEEE division); on the CPU (the oracle) it is a plain division.  The
-// two are the same function iff the device sequence returns the correctly rounded quotient for EVERY float in that range — which
-// this program checks, all ~1.57e9 of them, against the compiler's IEEE division on the same device.
+// fg_tanh needs num / den with num = x P(x^2), den = Q(x^2), |x| <= 9.  On the device that quotient is formed from v_rcp_f32 and fma
+// refinement steps (about half the instruction slots of the compiler's general IEEE division); on the CPU (the oracle) it is a
+// plain division.  The two are the same function iff the device sequence returns the correctly rounded quotient for EVERY pair the
+// function can form — which this program checks, one float x at a time (1.09e9 of them), against the compiler's IEEE division
+// on the same device.
 //   build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tests/div_exhaustive.hip -o tests/_build/div_exhaustive
 #include <hip/hip_runtime.h>
 
@@ -17,9 +19,9 @@ __global__ void __launch_bounds__(256) check(uint32_t first, uint32_t last, unsi
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     unsigned long long mine = 0;
     for (uint64_t u = (uint64_t)first + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; u <= last; u += stride) {
-        const float a = fg_u2f((uint32_t)u);
-        const float b = a + 2.0f;
-        const float fast = fg_div_em1(a, b);
+        float a, b;
+        fg_tanh_parts(fg_u2f((uint32_t)u), &a, &b);  // every |x| in [0, 9]: the pairs fg_tanh divides
+        const float fast = fg_div_tanh(a, b);
         const float ieee = a / b;
         if (fg_f2u(fast) != fg_f2u(ieee)) {
             ++mine;
@@ -92,7 +94,7 @@ static int run_check(K kernel, const char* what, unsigned long long* d_bad, uint
 
 int main()
 {
-    const uint32_t last = 0x5c800000u;  // 2^58 > e^40 = 2.35e17: every em1 fg_tanh can produce (its argument is clamped to 40)
+    const uint32_t last = 0x41100000u;  // bits of 9.0f = FG_TANH_MAX: every |x| fg_tanh evaluates its rational at
     unsigned long long* d_bad;
     uint32_t* d_first;
     unsigned long long bad = 0;
@@ -104,7 +106,7 @@ int main()
     if (hipDeviceSynchronize() != hipSuccess) return 2;
     (void)hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost);
     (void)hipMemcpy(&first_bad, d_first, 4, hipMemcpyDeviceToHost);
-    std::printf("fg_div_em1 vs IEEE division on %llu inputs: %llu mismatches", (unsigned long long)last + 1ull, bad);
+    std::printf("fg_div_tanh vs IEEE division on %llu inputs: %llu mismatches", (unsigned long long)last + 1ull, bad);
     if (bad) std::printf(" (first at bits 0x%08x)", first_bad);
     std::printf("\n");
     unsigned long long bad3 = 0;

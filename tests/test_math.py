@@ -11,16 +11,19 @@ def _ulp_err(y, exact):
 
 
 def test_exp_log_accuracy_sampled():
-    """Sampled version of tools/check_math.c (which is exhaustive: exp 0.91, log 0.93, log1p 1.48, tanh 2.61 ulp)."""
+    """Sampled version of tools/check_math.c (which is exhaustive: exp 0.91, log 1.20, log1p 1.29 ulp; tanh 3.8 ulp on |x| <= 2,
+    5.8 ulp where it saturates)."""
     rng = np.random.RandomState(0)
     x = np.concatenate([rng.uniform(-87, 40, 2_000_000), rng.uniform(-1, 1, 500_000)]).astype(np.float32)
     assert _ulp_err(O.math_apply("exp", x), np.exp(x.astype(np.float64))).max() < 1.0
     x = np.exp(rng.uniform(np.log(1e-7), np.log(5e7), 2_000_000)).astype(np.float32)
-    assert _ulp_err(O.math_apply("log", x), np.log(x.astype(np.float64))).max() < 1.0
+    assert _ulp_err(O.math_apply("log", x), np.log(x.astype(np.float64))).max() < 1.25
     u = np.exp(rng.uniform(np.log(1e-9), np.log(1.6e7), 2_000_000)).astype(np.float32)
     assert _ulp_err(O.math_apply("log1p", u), np.log1p(u.astype(np.float64))).max() < 1.6
     t = rng.uniform(-12, 12, 1_000_000).astype(np.float32)
-    assert _ulp_err(O.math_apply("tanh", t), np.tanh(t.astype(np.float64))).max() < 2.8
+    assert _ulp_err(O.math_apply("tanh", t), np.tanh(t.astype(np.float64))).max() < 5.9
+    t = rng.uniform(-2, 2, 1_000_000).astype(np.float32)
+    assert _ulp_err(O.math_apply("tanh", t), np.tanh(t.astype(np.float64))).max() < 3.9
 
 
 def test_phi_reference_clip_behaviour():
@@ -60,14 +63,14 @@ def test_philox_known_answers():
 
 @pytest.mark.gpu
 def test_device_division_sequences_equal_ieee_division_exhaustively():
-    """fg_tanh's quotient em1/(em1+2) and the mean's x/3 are plain divisions on the CPU and short rcp/fma sequences on the device
-    (fgnn_math.h: fg_div_em1, fg_div3).  tests/div_exhaustive.hip runs both against the compiler's IEEE division on the GPU for
-    every float of their domains (1.55e9 and 4.28e9 inputs): zero mismatches is what makes the two builds one function."""
+    """fg_tanh's quotient x P(x^2) / Q(x^2) and the mean's x/3 are plain divisions on the CPU and short rcp/fma sequences on the device
+    (fgnn_math.h: fg_div_tanh, fg_div3).  tests/div_exhaustive.hip runs both against the compiler's IEEE division on the GPU for
+    every float of their domains (1.09e9 and 4.28e9 inputs): zero mismatches is what makes the two builds one function."""
     import subprocess
     import __graft_entry__ as entry
     res = subprocess.run([entry.build_div_exhaustive()], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert res.returncode == 0, res.stdout
-    assert "fg_div_em1 vs IEEE division on 1551892481 inputs: 0 mismatches" in res.stdout
+    assert "fg_div_tanh vs IEEE division on 1091567617 inputs: 0 mismatches" in res.stdout
     assert "fg_div3 vs IEEE division on all finite floats: 0 mismatches" in res.stdout
     assert "fg_div_atanh vs IEEE division on every a in [0, 1 - 2^-23]: 0 mismatches" in res.stdout
     assert "fg_rcp_unit vs IEEE division on all finite floats: 0 mismatches" in res.stdout

@@ -65,7 +65,8 @@ int main(void)
     sweep("exp", w_exp, exp, 0.0f, 40.0f);
     sweep("log", w_log, log, 1e-7f, 5e7f);
     sweep("log1p", w_log1p, log1p, 0.0f, 16777216.0f);
-    sweep("tanh", w_tanh, tanh, 0.0f, 12.0f);
+    sweep("tanh", w_tanh, tanh, 0.0f, 2.0f);
+    sweep("tanh", w_tanh, tanh, 2.0f, 12.0f);
     sweep("atanh", w_atanh, atanh, 0.0f, 0.99999988f);
     /* phi: the f32 formula cancels for large x, so only the well-conditioned part is an accuracy check */
     sweep("phi<8", w_phi, d_phi, 1e-7f, 8.0f);
