@@ -595,6 +595,87 @@ def test_north_star_full_size_properties_and_strided_oracle_check():
     assert torch.equal(cp["x_hat"], full["x_hat"]) and torch.equal(cp["z_hat"], full["z_hat"])
 
 
+def test_config3_full_shard_properties_and_strided_oracle_check():
+    """BASELINE.json configs[3]: [[1270,28]], sandwich (64, G, 64) with the trained weights (/root/reference n1270.py:37,57), at
+    the per-GPU shard of the 8-GPU run: 262 144 / 8 = 32 768 codewords.  Same size-independent properties as the north-star test:
+    (i) every 256th sample equals the oracle bit for bit (decisions, marginals, rounds), (ii) unflagged samples reproduce both
+    syndromes and flags imply block errors, (iii) a permuted batch gives permuted results, (iv) compact == full, (v) the shard
+    decoded as rank 3 of 8 of the global Philox stream equals the same samples decoded in one piece."""
+    from feedback_gnn_amd.graph import GnnWeights
+    from feedback_gnn_amd.weights_io import read_weight_list
+    name, B, p = "ghp1270", 32768, 0.05
+    og, gg = oracle_graph(name), gpu_graph(name)
+    c = code(name)
+    w = read_weight_list(WEIGHTS_1270)
+    gw = GnnWeights(w, gg.device)
+    L0 = llr_const(0.05)
+    first = 3 * B  # rank 3 of 8: global samples [3B, 4B)
+    ex, ez = gg.pauli_noise(SEED, p, first, B)
+    sx, sz = gg.syndrome(ex, ez)
+    full = gg.sandwich_decode(sx, sz, [64, 64], [gw], L0, return_llr=True, return_rounds=True)
+    idx = torch.arange(0, B, 256, device=gg.device)
+    oex, oez = og.pauli_noise(SEED, p, first, B)  # the oracle's own Philox stream: same global sample indices
+    assert np.array_equal(oex[::256], ex[idx].cpu().numpy()) and np.array_equal(oez[::256], ez[idx].cpu().numpy())
+    osx, osz = og.syndrome(oex[::256], oez[::256])
+    o = og.sandwich_decode(osx, osz, [64, 64], [w], L0, return_llr=True)
+    assert np.array_equal(o["x_hat"], full["x_hat"][idx].cpu().numpy())
+    assert np.array_equal(o["z_hat"], full["z_hat"][idx].cpu().numpy())
+    assert np.array_equal(o["llr"], full["llr"][idx].cpu().numpy())
+    assert np.array_equal(o["rounds"], full["rounds"][idx].cpu().numpy())
+    assert int(full["rounds"].sum()) > 0, "p = 0.05 must send some samples through the feedback round"
+    s_hat, ls_hat, flags = gg.residual(ex, ez, full["x_hat"], full["z_hat"])
+    ok = (flags & 1) == 0
+    hx_t = torch.from_numpy(c.hx.astype(np.float32)).to(gg.device)
+    hz_t = torch.from_numpy(c.hz.astype(np.float32)).to(gg.device)
+    assert torch.equal((full["z_hat"].float() @ hx_t.t()).remainder(2).to(torch.uint8)[ok], sx[ok])
+    assert torch.equal((full["x_hat"].float() @ hz_t.t()).remainder(2).to(torch.uint8)[ok], sz[ok])
+    assert bool((s_hat[ok] == 0).all()) and bool((((flags >> 1) & 1) >= (flags & 1)).all())
+    assert int(ok.sum()) > 0.99 * B
+    perm = torch.randperm(B, device=gg.device, generator=torch.Generator(device=gg.device).manual_seed(2))
+    pr = gg.sandwich_decode(sx[perm].contiguous(), sz[perm].contiguous(), [64, 64], [gw], L0, return_llr=True)
+    assert torch.equal(pr["x_hat"], full["x_hat"][perm]) and torch.equal(pr["z_hat"], full["z_hat"][perm])
+    assert torch.equal(pr["llr"], full["llr"][perm])
+    cp = gg.sandwich_decode(sx, sz, [64, 64], [gw], L0, compact=True)
+    assert torch.equal(cp["x_hat"], full["x_hat"]) and torch.equal(cp["z_hat"], full["z_hat"])
+    # (v) sharding: the model class with rank = 3, world_size = 8 draws exactly these samples for its first batch
+    import feedback_gnn_amd as F
+    d0 = F.QLDPCBPDecoder(code=c, num_iter=64, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True, graph=gg)
+    G = F.Feedback_GNN(code=c, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean", activation="tanh",
+                       use_bias=True, graph=gg)
+    F.load_weights(G, WEIGHTS_1270)
+    m = F.Sandwich_BP_GNN_Evaluation_Model(c, [d0, d0], [G], num_layers=2, rank=3, world_size=8, seed=SEED)
+    d = m.decode(B, p)
+    assert torch.equal(d["noise_x"], ex) and torch.equal(d["x_hat"], full["x_hat"]) and torch.equal(d["z_hat"], full["z_hat"])
+
+
+def test_config4_full_shard_gnn_bp4_properties_and_strided_oracle_check():
+    """BASELINE.json configs[4]: [[1270,28]] GNN_BP4 (/root/reference sionna/fec/ldpc/gnn.py:383-423, repaired arity), 10
+    iterations, at the per-GPU shard of the 8-GPU run: 131 072 / 8 = 16 384 codewords.  (i) every 512th sample (32 samples)
+    equals the oracle bit for bit — marginals, hard decisions and the soft syndromes of every iteration; (ii) a permuted batch
+    gives permuted results; (iii) the decoder is a function of the syndrome alone: duplicated syndromes give duplicated rows."""
+    from feedback_gnn_amd.graph import GnnBp4Weights
+    name, B, iters = "ghp1270", 16384, 10
+    og, gg = oracle_graph(name), gpu_graph(name)
+    w = _gnnbp4_weights(5)
+    gw = GnnBp4Weights(w, gg.device)
+    ex, ez = gg.pauli_noise(SEED, 0.05, 7 * B, B)
+    sx, sz = gg.syndrome(ex, ez)
+    sx[1], sz[1] = sx[0], sz[0]  # (iii)
+    full = gg.gnn_bp4_decode(gw, sx, sz, iters)
+    idx = torch.arange(0, B, 512, device=gg.device)
+    o = og.gnn_bp4(w, sx[idx].cpu().numpy(), sz[idx].cpu().numpy(), iters)
+    for k in ("llr", "x_hat", "z_hat"):
+        assert np.array_equal(o[k], full[k][idx].cpu().numpy()), k
+    for k in ("x_logit_all", "z_logit_all"):
+        assert np.array_equal(o[k], full[k][:, idx].cpu().numpy()), k
+    assert torch.equal(full["llr"][0], full["llr"][1]) and torch.equal(full["x_hat"][0], full["x_hat"][1])
+    assert bool(torch.isfinite(full["llr"]).all())
+    perm = torch.randperm(B, device=gg.device, generator=torch.Generator(device=gg.device).manual_seed(3))
+    pr = gg.gnn_bp4_decode(gw, sx[perm].contiguous(), sz[perm].contiguous(), iters, return_logits=False)
+    assert torch.equal(pr["llr"], full["llr"][perm]) and torch.equal(pr["x_hat"], full["x_hat"][perm])
+    assert torch.equal(pr["z_hat"], full["z_hat"][perm])
+
+
 @pytest.mark.parametrize("name", ["gb46_oc", "gb48_oc"])
 @pytest.mark.parametrize("cn_type", ["boxplus-phi", "minsum"])
 def test_reference_overcomplete_codes_bit_exact(name, cn_type):
