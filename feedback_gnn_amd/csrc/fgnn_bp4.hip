@@ -18,6 +18,8 @@
 //
 // Summation order is the canonical one of the oracle (ascending neighbour index) and every
 // float op is the one the oracle executes, so results are bit-identical to oracle/fgnn_oracle.c.
+#include <cstdlib>
+
 #include "fgnn_internal.h"
 #include "fgnn_math.h"
 
@@ -49,6 +51,7 @@ struct BpArgs {
     int shortcut;             // 1: wave-uniform exact shortcuts for saturated nodes (regular kernel)
     int early_exit;           // 1: leave the iteration loop at a proven fixed point (needs shortcut, cpb == 1, phi rule)
     int sig_off;              // float offset of the fixed-point detector's LDS words (n sign words + 4 flags)
+    int lreg;                 // 4 / 5: channel LLRs in registers (kernel variant NQ = lreg), 0: in LDS
     int hwt;                  // 1: v_exp_f32 / v_log_f32 instead of fgnn_math.h (FGNN_OPT_HW_TRANSCENDENTALS; phi rule, fixed dataflow)
     uint8_t* flagged;         // optional [B]: 1 iff the decision's syndrome differs from the measured one (feedback_gnn.py:324-328)
     int flag_off;             // float offset of n decision bytes + one word in LDS (only when flagged != null)
@@ -341,13 +344,20 @@ __device__ __forceinline__ float softplus_saturated(float t)
 // 16-byte row of g.cslot16.  DVX = 0: runtime degrees through the CSR tables.
 // OPT = false compiles the exact optimisations (saturation shortcut, fixed-point detector) out: the fixed-dataflow
 // variant bench.py's headline times carries none of their tests.
-template <int CN_TYPE, int DVX, int DVZ, int DC, bool OPT, bool HWT = false>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FGNN_BP4_WAVES))) bp4_kernel(GraphDev g, BpArgs a)
+// NQ > 0: per-qubit channel LLRs (llr_ch != null: every decoder of a sandwich but the first) live in REGISTERS, 3 x NQ per thread
+// for the at most NQ qubits lane, lane + tpc, ... a thread owns, instead of 3n floats of LDS: the workgroup then needs the message
+// area only and 7 instead of 4 ([[882,24]]) / 5 instead of 3 ([[1270,28]]) workgroups share a CU; the register budget is that of
+// 6 waves per SIMD.  The launch picks NQ = ceil(n / tpc) when that is 4 or 5.
+template <int CN_TYPE, int DVX, int DVZ, int DC, bool OPT, bool HWT = false, int NQ = 0>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NQ > 0 ? FGNN_BP4_WAVES - 1 : FGNN_BP4_WAVES)))
+bp4_kernel(GraphDev g, BpArgs a)
 {
     static_assert(!(HWT && OPT), "the hardware-transcendental variant is the fixed dataflow only: the exact shortcuts are proofs about fgnn_math.h");
     using MX = Mx<HWT>;
     FG_LOG_TAB_SETUP();
     constexpr bool REGULAR = DVX > 0;
+    constexpr bool LREG = NQ > 0;
+    constexpr int NQA = LREG ? NQ : 1;
     const bool opt_shortcut = OPT && a.shortcut != 0;
     const bool opt_exit = OPT && a.early_exit != 0;
     extern __shared__ float lds[];
@@ -368,8 +378,18 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FGNN_
         for (int e = lane; e < g.E_x; e += a.tpc) msg[e] = a.msg_init_x ? a.msg_init_x[(size_t)b * g.E_x + e] : 0.0f;
         for (int e = lane; e < g.E_z; e += a.tpc)
             msg[g.E_x + e] = a.msg_init_z ? a.msg_init_z[(size_t)b * g.E_z + e] : 0.0f;
-        if (a.llr_ch)
+        if (a.llr_ch && !LREG)
             for (int i = lane; i < 3 * n; i += a.tpc) Lch[i] = a.llr_ch[(size_t)b * 3 * n + i];
+    }
+    float lreg[3][NQA];  // LREG: channel LLRs of qubits lane + i * tpc
+    if constexpr (LREG) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int v = lane + i * a.tpc;
+            const bool in = active && v < n;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) lreg[c][i] = in ? a.llr_ch[(size_t)b * 3 * n + c * n + v] : 0.0f;
+        }
     }
     __syncthreads();
 
@@ -428,11 +448,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FGNN_
     for (int it = it_begin; it < a.num_iter; ++it) {
         bool changed = false, cn_slow = false;
         // ---- variable nodes: _vn_update (:227-275) ----
-        if (active)
-            for (int v = lane; v < n; v += a.tpc) {
-                const float lx = a.llr_ch ? Lch[v] : a.llr_const;
-                const float ly = a.llr_ch ? Lch[n + v] : a.llr_const;
-                const float lz = a.llr_ch ? Lch[2 * n + v] : a.llr_const;
+        auto vn_body = [&](const int v, const float lx, const float ly, const float lz) __attribute__((always_inline)) {
                 if constexpr (REGULAR) {
                     float* px = msg + v * DVX;
                     float* pz = msg + g.E_x + v * DVZ;
@@ -476,7 +492,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FGNN_
                             const float Xe = X - mz[k], Ye = Y - mz[k];
                             pz[k] = numz - (0.0f + FG_MAX(-Xe, -Ye));
                         }
-                        continue;
+                        return;
                     }
                     const float numx = MX::softplus(-X);
                     const float numz = MX::softplus(-Z);
@@ -527,7 +543,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FGNN_
                                 const float Xe = X - mm, Ye = Y - mm;
                                 msg[e] = nz - (0.0f + FG_MAX(-Xe, -Ye));
                             }
-                            continue;
+                            return;
                         }
                     }
                     const float numx = MX::softplus(-X);
@@ -543,7 +559,21 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FGNN_
                         msg[e] = numz - MX::lse2(-Xe, -Ye);
                     }
                 }
+            };
+        if (active) {
+            if constexpr (LREG) {
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    const int v = lane + i * a.tpc;
+                    if (v < n) vn_body(v, lreg[0][i], lreg[1][i], lreg[2][i]);
+                }
+            } else {
+                for (int v = lane; v < n; v += a.tpc) {
+                    if (a.llr_ch) vn_body(v, Lch[v], Lch[n + v], Lch[2 * n + v]);
+                    else vn_body(v, a.llr_const, a.llr_const, a.llr_const);
+                }
             }
+        }
         if (opt_exit && changed) flags[2 * (it & 1)] = 1;
         __syncthreads();
         // ---- check nodes of both graphs (:752-767) ----
@@ -591,15 +621,11 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FGNN_
     }
     // The binary LLRs go to LDS where the messages were; totals are computed first by every thread,
     // parked in global memory (llr_out), and only then may the message area be overwritten.
-    if (active)
-        for (int v = lane; v < n; v += a.tpc) {
+    auto total_body = [&](const int v, const float lx, const float ly, const float lz) __attribute__((always_inline)) {
             const int x0 = g.vptr_x[v], x1 = g.vptr_x[v + 1], z0 = g.vptr_z[v], z1 = g.vptr_z[v + 1];
             float Sz = 0.0f, Sx = 0.0f;
             for (int e = z0; e < z1; ++e) Sz = Sz + msg[e];
             for (int e = x0; e < x1; ++e) Sx = Sx + msg[e];
-            const float lx = a.llr_ch ? Lch[v] : a.llr_const;
-            const float ly = a.llr_ch ? Lch[n + v] : a.llr_const;
-            const float lz = a.llr_ch ? Lch[2 * n + v] : a.llr_const;
             const float Y = (Sz + Sx) + ly;
             const float X = Sz + lx;
             const float Z = Sx + lz;
@@ -614,13 +640,33 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FGNN_
             if (Y < best) { best = Y; d = 3; }
             a.x_hat[(size_t)b * n + v] = (uint8_t)(d & 1);
             a.z_hat[(size_t)b * n + v] = (uint8_t)(d >> 1);
-            if (a.flagged) reinterpret_cast<uint8_t*>(msg + a.flag_off)[v] = (uint8_t)d;
+    };
+    if (active) {
+        if constexpr (LREG) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int v = lane + i * a.tpc;
+                if (v < n) total_body(v, lreg[0][i], lreg[1][i], lreg[2][i]);
+            }
+        } else {
+            for (int v = lane; v < n; v += a.tpc) {
+                if (a.llr_ch) total_body(v, Lch[v], Lch[n + v], Lch[2 * n + v]);
+                else total_body(v, a.llr_const, a.llr_const, a.llr_const);
+            }
         }
+    }
     if (a.flagged) {
         // Fused flag test of the sandwich (feedback_gnn.py:324-328): does the estimate reproduce the measured syndrome?  hx rows
-        // check z_hat (bit 1 of the decision), hz rows x_hat (bit 0); the decisions of this codeword sit in LDS.
+        // check z_hat (bit 1 of the decision), hz rows x_hat (bit 0).  The decisions of this codeword go to LDS — into the message
+        // area once every thread is done reading messages (flag_off points there whenever the area is large enough: the n bytes
+        // then cost no LDS of their own, which is what lets five [[882,24]] workgroups with per-qubit channel LLRs share a CU).
         uint8_t* dec = reinterpret_cast<uint8_t*>(msg + a.flag_off);
         unsigned* fword = reinterpret_cast<unsigned*>(dec + ((n + 3) & ~3));
+        __syncthreads();
+        if (active)
+            for (int v = lane; v < n; v += a.tpc) {  // the thread's own decisions again, from its own writes
+                dec[v] = (uint8_t)(a.x_hat[(size_t)b * n + v] | (a.z_hat[(size_t)b * n + v] << 1));
+            }
         if (lane == 0) *fword = 0u;
         __syncthreads();
         unsigned mine = 0;
@@ -675,6 +721,10 @@ int launch_bp4_k(const fgnn_graph* g, const BpArgs& a, const LaunchGeom& L, size
     auto kern = a.shortcut ? bp4_kernel<CN_TYPE, DVX, DVZ, DC, true> : bp4_kernel<CN_TYPE, DVX, DVZ, DC, false>;
     if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI) {
         if (a.hwt) kern = bp4_kernel<CN_TYPE, DVX, DVZ, DC, false, true>;  // opt-in, fixed dataflow (fgnn_graph_set_option 3)
+        if constexpr (DVX == 3 && DVZ == 3 && DC == 6) {
+            if (a.lreg == 4) kern = a.shortcut ? bp4_kernel<CN_TYPE, DVX, DVZ, DC, true, false, 4> : bp4_kernel<CN_TYPE, DVX, DVZ, DC, false, false, 4>;
+            if (a.lreg == 5) kern = a.shortcut ? bp4_kernel<CN_TYPE, DVX, DVZ, DC, true, false, 5> : bp4_kernel<CN_TYPE, DVX, DVZ, DC, false, false, 5>;
+        }
     }
     if (lds_bytes > 48 * 1024)
         FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -733,9 +783,18 @@ int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float n
     a.index = index;
     a.hwt = (g->hw_transcendentals && cn_type == FGNN_CN_BOXPLUS_PHI) ? 1 : 0;
     a.shortcut = (g->shortcut && !a.hwt) ? 1 : 0;
-    // floats per codeword: messages (>= 2n so the epilogue's binary LLRs fit) + channel LLRs
+    // floats per codeword: messages (>= 2n so the epilogue's binary LLRs fit) + channel LLRs (unless they fit the registers of
+    // the NQ variant: regular (3,3,6) graph, phi rule, exact math, one codeword per workgroup, 4 or 5 qubits per thread)
     a.lch_off = g->d.E > 2 * g->d.n ? g->d.E : 2 * g->d.n;
-    int per_cw = a.lch_off + (llr_ch ? 3 * g->d.n : 0);
+    a.lreg = 0;
+    {
+        static const bool no_lreg = getenv("FGNN_BP4_NO_LREG") != nullptr;  // A/B knob (tools/ab_bp4_lch.py)
+        const int per_thread = (g->d.n + L.tpc - 1) / L.tpc;
+        if (llr_ch && !no_lreg && !a.hwt && cn_type == FGNN_CN_BOXPLUS_PHI && L.cpb == 1 && g->d.cslot16 && !g->force_generic &&
+            g->d.dvx == 3 && g->d.dvz == 3 && g->d.dc == 6 && per_thread <= 5)
+            a.lreg = per_thread <= 4 ? 4 : 5;
+    }
+    int per_cw = a.lch_off + ((llr_ch && !a.lreg) ? 3 * g->d.n : 0);
     per_cw = (per_cw + 3) & ~3;
     a.lds_per_cw = per_cw;
     size_t lds_bytes = (size_t)per_cw * sizeof(float) * (size_t)L.cpb;
@@ -752,10 +811,20 @@ int fgnn_bp4_decode_impl(const fgnn_graph* g, int cn_type, int num_iter, float n
     }
     a.flagged = flagged;
     a.flag_off = 0;
-    if (flagged) {  // n decision bytes + one word per codeword, behind everything else
+    if (flagged) {  // n decision bytes + one word per codeword: inside the message area (behind the 2n floats the soft-syndrome
+                    // epilogue reuses) when it is large enough, else behind everything else
         if (L.cpb != 1) return fgnn_fail(FGNN_ERR_STATE, "the fused flag test needs one codeword per workgroup");
-        a.flag_off = (int)(lds_bytes / sizeof(float));
-        lds_bytes += (size_t)((g->d.n + 3) & ~3) + sizeof(unsigned);
+        const size_t need = (size_t)((g->d.n + 3) & ~3) + sizeof(unsigned);
+        if ((size_t)a.lch_off * sizeof(float) >= (size_t)2 * g->d.n * sizeof(float) + need) {
+            a.flag_off = 2 * g->d.n;
+        } else {
+            a.flag_off = (int)(lds_bytes / sizeof(float));
+            lds_bytes += need;
+        }
+    }
+    {  // experiment knob (tools/ab_bp4_lch.py): pad the dynamic LDS to lower the number of resident workgroups
+        static const long pad = getenv("FGNN_BP4_LDS_PAD") ? atol(getenv("FGNN_BP4_LDS_PAD")) : 0;
+        if (pad > 0 && lds_bytes + (size_t)pad <= FGNN_LDS_BUDGET) lds_bytes += (size_t)pad;
     }
     if (lds_bytes > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident kernel");
     hipStream_t st = static_cast<hipStream_t>(stream);

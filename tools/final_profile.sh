@@ -17,6 +17,14 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_C
   timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $O/pmc_$tag -- python3 tools/prof_kernels.py ghp882 65536 fixed > $O/pmc_$tag.log 2>&1
 done
 python tools/pmc_summary.py $O/pmc_*/*/*_counter_collection.csv > $O/pmc_summary.txt
+# GNN_BP4 (BASELINE configs[4]) at its per-GPU shard shape, 16 384 codewords x 10 iterations: timing + the same counter passes
+python tools/bench_gnnbp4.py 16384 > $O/gnnbp4_c5shape.txt 2>&1 || true
+for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_WAIT_INST_LDS"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $O/c5pmc_$tag -- python3 tools/prof_gnnbp4.py 16384 > $O/c5pmc_$tag.log 2>&1
+done
+python tools/pmc_summary.py $O/c5pmc_*/*/*_counter_collection.csv > $O/c5_pmc_summary.txt
+cat $O/gnnbp4_c5shape.txt
 python tools/dispatch_summary.py $O/trace/*/*_kernel_trace.csv > $O/dispatches.txt
 cat $O/dispatches.txt
 grep -E "bp4_kernel.*b12 (FETCH|WRITE|SQ_INSTS_VALU |GRBM)" $O/pmc_summary.txt

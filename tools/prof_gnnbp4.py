@@ -1,8 +1,9 @@
+"""Launch the GNN_BP4 kernel at the C5 shard shape (for rocprofv3 --kernel-trace / --pmc passes): python3 tools/prof_gnnbp4.py [B]"""
 import sys, torch, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from helpers import code
 from feedback_gnn_amd.graph import TannerGraph, GnnBp4Weights, GNNBP4_SHAPES
-B = 4096
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384  # BASELINE configs[4]: 131 072 / 8 GPUs
 g = TannerGraph(code('ghp1270'))
 rng = np.random.RandomState(0)
 w = GnnBp4Weights([rng.uniform(-0.3, 0.3, size=s).astype(np.float32) for s in GNNBP4_SHAPES], g.device)
