@@ -27,4 +27,6 @@ python tools/pmc_summary.py $O/c5pmc_*/*/*_counter_collection.csv > $O/c5_pmc_su
 cat $O/gnnbp4_c5shape.txt
 python tools/dispatch_summary.py $O/trace/*/*_kernel_trace.csv > $O/dispatches.txt
 cat $O/dispatches.txt
-grep -E "bp4_kernel.*b12 (FETCH|WRITE|SQ_INSTS_VALU |GRBM)" $O/pmc_summary.txt
+python tools/make_traffic_json.py $O/pmc_summary.txt "$TAG" > $O/traffic.json
+python tools/harness_rate.py 0.05 3 40 2>&1 | grep "^(" > $O/harness_rate.txt || true
+grep -E "bp4_kernel.* (FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU |GRBM_GUI_ACTIVE)" $O/pmc_summary.txt || true

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from a tools/pmc_summary.py summary (the rocprofv3 --pmc passes of tools/final_profile.sh): HBM bytes and VALU
+wave-instructions per launch of the 64-iteration BP4 kernel and of the feedback-GNN kernel at the benchmark shape.  bench.py quotes
+these under roofline.traffic / roofline.valu with their source: they are offline measurements, not taken by the bench run itself.
+
+    python tools/make_traffic_json.py gpurun_out/r2z/pmc_summary.txt <tag> > profiles/traffic.json
+"""
+import json
+import re
+import sys
+
+path, tag = sys.argv[1], sys.argv[2]
+rows = {}
+for line in open(path):
+    m = re.match(r"(\S.*?)\s+grid=\s*(\d+)\s+wg=\s*(\S+)\s+(\S+)\s+mean=(\S+)\s+n=(\d+)\s+avg_ms=(\S+)", line)
+    if m:
+        rows.setdefault((m.group(1).strip(), m.group(3)), {})[m.group(4)] = (float(m.group(5)), float(m.group(7)))
+
+
+def pick(prefix, want_longest=True):
+    cands = [(k, v) for k, v in rows.items() if k[0].startswith(prefix) and "FETCH_SIZE" in v]
+    cands.sort(key=lambda kv: kv[1]["FETCH_SIZE"][1], reverse=want_longest)
+    return cands[0] if cands else None
+
+
+out = {}
+bp = pick("bp4_kernel")
+if bp:
+    (name, wg), v = bp
+    fetch_kb, write_kb = v["FETCH_SIZE"][0], v["WRITE_SIZE"][0]
+    out["bp4_ghp882_it64_B65536"] = {
+        "kernel": name, "taken_at": tag, "avg_ms_under_pmc": v["SQ_INSTS_VALU"][1] if "SQ_INSTS_VALU" in v else None,
+        "fetch_size_kb_raw": fetch_kb, "write_size_kb_raw": write_kb,
+        "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
+        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (gfx950 "
+                "reports half the bytes of wide reads; byte-granular reads are uncalibrated, so this is an upper bound); WRITE_SIZE is "
+                "exact: marginals + decisions + soft syndromes",
+        "valu_wave_insts_per_launch": v.get("SQ_INSTS_VALU", (None,))[0],
+        "valu_note": "SQ_INSTS_VALU of the same launch; a wave64 VALU instruction occupies a SIMD-32 for 2 cycles",
+        "lds_idx_active": v.get("SQ_LDS_IDX_ACTIVE", (None,))[0], "lds_bank_conflict": v.get("SQ_LDS_BANK_CONFLICT", (None,))[0],
+        "grbm_gui_active": v.get("GRBM_GUI_ACTIVE", (None,))[0],
+    }
+gn = pick("gnn_mfma_kernel")
+if gn:
+    (name, wg), v = gn
+    out["gnn_ghp882_B65536"] = {
+        "kernel": name, "taken_at": tag, "avg_ms_under_pmc": v["SQ_INSTS_VALU"][1] if "SQ_INSTS_VALU" in v else None,
+        "hbm_bytes_per_launch": int(2 * v["FETCH_SIZE"][0] * 1024 + v["WRITE_SIZE"][0] * 1024),
+        "valu_wave_insts_per_launch": v.get("SQ_INSTS_VALU", (None,))[0], "mfma_insts_per_launch": v.get("SQ_INSTS_MFMA", (None,))[0],
+        "mfma_busy_cycles": v.get("SQ_VALU_MFMA_BUSY_CYCLES", (None,))[0], "grbm_gui_active": v.get("GRBM_GUI_ACTIVE", (None,))[0],
+    }
+print(json.dumps(out, indent=1))
