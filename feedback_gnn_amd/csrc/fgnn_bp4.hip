@@ -9,7 +9,7 @@
 // The reference streams every [E,bs] message tensor through HBM ~10 times per half-iteration.
 // Here a codeword's state (E floats of messages + 3n channel LLRs, 32 KB for [[882,24]]) never
 // leaves the CU: HBM sees the syndromes once and the results once.  The kernel is therefore bound
-// by VALU issue (about 10^3 fma-class ops per qubit-iteration for the exact exp/log of
+// by VALU issue (about 830 fma-class ops per qubit-iteration for the exact exp/log of
 // fgnn_math.h), not by HBM; DESIGN.md §4 gives the accounting next to the streaming-model figure.
 //
 // Message layout in LDS: slot e in [0,E_x) = hx edges, [E_x,E) = hz edges, both sorted by
