@@ -115,16 +115,20 @@ __device__ __forceinline__ void mlp_tile(const float* __restrict__ lane_tab, int
     out[4] = m1[0] + b2[4 * 64];
 }
 
-// row of D floats as the 5 B-operand registers of lane group q: element 4s+q for s = 0..4
+// A node's D = 20 embedding floats as the 5 B-operand registers of lane group q: element 4s+q for s = 0..4.  The MFMA kernel keeps
+// its workspace rows in that order — [q][s], element 4s+q at q*5+s — so a lane's five values are 20 contiguous bytes (one 16-byte and
+// one 4-byte access instead of five strided ones).  The layout is private to the kernel: rows are only ever read and written here.
 __device__ __forceinline__ void load_row5(const float* row, int q, float (&r)[5])
 {
+    const float* p = row + q * 5;
 #pragma unroll
-    for (int s = 0; s < 5; ++s) r[s] = row[4 * s + q];
+    for (int s = 0; s < 5; ++s) r[s] = p[s];
 }
 __device__ __forceinline__ void store_row5(float* row, int q, const float (&r)[5])
 {
+    float* p = row + q * 5;
 #pragma unroll
-    for (int s = 0; s < 5; ++s) row[4 * s + q] = r[s];
+    for (int s = 0; s < 5; ++s) p[s] = r[s];
 }
 
 struct Args {
@@ -291,6 +295,7 @@ __global__ void __launch_bounds__(512, 2) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4
     float* lx = lds + tab_floats;
     float* lz = lx + n;
     float* hlog = lz + n;
+    float* ssg = hlog + m;  // [m] syndrome signs 1 - 2 s as floats (hx checks, then hz): read once from HBM, not once per edge
     float* hv = a.work + (size_t)b * (size_t)(n + m) * D;
     float* hc = hv + (size_t)n * D;
     const uint8_t* sx = a.synd_x + (size_t)b * mx;
@@ -298,7 +303,10 @@ __global__ void __launch_bounds__(512, 2) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4
     const int rxp = mz + g.rows[5], rzp = mx + g.rows[4];
     for (int i = tid; i < n * D; i += T) hv[i] = 1.0f;
     for (int i = tid; i < m * D; i += T) hc[i] = 0.0f;
-    for (int c = tid; c < m; c += T) hlog[c] = 0.0f;
+    for (int c = tid; c < m; c += T) {
+        hlog[c] = 0.0f;
+        ssg[c] = ((c < mx ? sx[c] : sz[c - mx]) & 1) ? -1.0f : 1.0f;
+    }
     float* llr = a.llr_out + (size_t)b * 3 * n;
     const int l = tid & 63, wave = tid >> 6, j = l & 15, q = l >> 4;
     const float* tab = tabs + l;
@@ -317,20 +325,28 @@ __global__ void __launch_bounds__(512, 2) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4
                 const int v = valid ? vraw : n - 1;
                 float own[5], Bemb[15];
                 load_row5(hv + (size_t)v * D, q, own);
+                // all 2 x DV neighbour rows of the tile are requested before the first MLP starts: the gathers (L2-resident rows of
+                // other workgroups' making) then complete under ~1 600 cycles of MFMA work each instead of in front of it
+                int cn_of[2][DV];
+                float fnb[2][DV][5];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int k = 0; k < DV; ++k) {
+                        cn_of[s2][k] = g.vchk[(s2 ? g.E_x : 0) + v * DV + k];
+                        load_row5(hc + (size_t)((s2 ? mx : 0) + cn_of[s2][k]) * D, q, fnb[s2][k]);
+                    }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const int ebase = (s2 ? g.E_x : 0) + v * DV;
                     float acc[5];
 #pragma unroll
                     for (int k = 0; k < DV; ++k) {
-                        const int c = g.vchk[ebase + k];
+                        const int c = cn_of[s2][k];
                         float Bin[10], msg[5];
-                        float fr[5];
-                        load_row5(hc + (size_t)((s2 ? mx : 0) + c) * D, q, fr);
 #pragma unroll
-                        for (int s = 0; s < 5; ++s) { Bin[s] = fr[s]; Bin[5 + s] = own[s]; }
+                        for (int s = 0; s < 5; ++s) { Bin[s] = fnb[s2][k][s]; Bin[5 + s] = own[s]; }
                         mlp_tile<10>(tab, w.tab_vn_msg[s2] - vn_first, Bin, msg);
-                        const float sg = ((s2 ? sz[c] : sx[c]) & 1) ? -1.0f : 1.0f;
+                        const float sg = ssg[(s2 ? mx : 0) + c];
 #pragma unroll
                         for (int i = 0; i < 5; ++i) { const float mv = msg[i] * sg; acc[i] = (k == 0) ? mv : acc[i] + mv; }
                     }
@@ -391,21 +407,21 @@ __global__ void __launch_bounds__(512, 2) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4
             const int c = (s2 ? mx : 0) + (valid ? local : cnt - 1);  // combined check id
             float own[5], acc[5], Bemb[11];
             load_row5(hc + (size_t)c * D, q, own);
+            float fnb[DC][5];  // the DC neighbour rows, requested up front (see the qubit phase)
+#pragma unroll
+            for (int k = 0; k < DC; ++k) load_row5(hv + (size_t)g.cvn[c * DC + k] * D, q, fnb[k]);
 #pragma unroll
             for (int k = 0; k < DC; ++k) {
-                const int v = g.cvn[c * DC + k];
-                float Bin[10], msg[5], fr[5];
-                load_row5(hv + (size_t)v * D, q, fr);
+                float Bin[10], msg[5];
 #pragma unroll
-                for (int s = 0; s < 5; ++s) { Bin[s] = fr[s]; Bin[5 + s] = own[s]; }
+                for (int s = 0; s < 5; ++s) { Bin[s] = fnb[k][s]; Bin[5 + s] = own[s]; }
                 mlp_tile<10>(tab, w.tab_cn_msg[s2] - cn_first, Bin, msg);
 #pragma unroll
                 for (int i = 0; i < 5; ++i) acc[i] = (k == 0) ? msg[i] : acc[i] + msg[i];
             }
 #pragma unroll
             for (int i = 0; i < 5; ++i) { Bemb[i] = acc[i] / (float)DC; Bemb[5 + i] = own[i]; }
-            const unsigned sb = (s2 ? sz[c - mx] : sx[c]) & 1;
-            const float lg = (it >= 0) ? hlog[c] * (sb ? -1.0f : 1.0f) : 0.0f;
+            const float lg = (it >= 0) ? hlog[c] * ssg[c] : 0.0f;
             Bemb[10] = (q == 0) ? lg : 0.0f;
             float nh[5];
             mlp_tile<11>(tab, w.tab_cn_embed[s2] - cn_first, Bemb, nh);
@@ -591,7 +607,7 @@ extern "C" int fgnn_gnnbp4_decode(const fgnn_graph* g, const fgnn_gnnbp4_weights
     if (g->d.dvx == 3 && g->d.dvz == 3 && g->d.dc == 6 && !g->force_generic) {
         const int cn_entries = w->d.tab_vn_msg[0] - w->d.tab_cn_msg[0], vn_entries = w->d.tab_inv + 8 - w->d.tab_vn_msg[0];
         const int tab_floats = (cn_entries > vn_entries ? cn_entries : vn_entries) * 64;
-        const size_t lds2 = lds_bytes + (size_t)tab_floats * sizeof(float);
+        const size_t lds2 = lds_bytes + (size_t)(tab_floats + g->d.m) * sizeof(float);  // + the syndrome signs
         auto kern = gnn_bp4_mfma_kernel<3, 6>;
         if (lds2 > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "code too large for the GNN_BP4 MFMA kernel");
         FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
