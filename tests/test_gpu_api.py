@@ -260,3 +260,38 @@ def test_hw_transcendentals_are_opt_in_and_what_they_cost_in_fidelity():
     assert np.isfinite(mx_hw).all() and (np.abs(mx_hw - np.array([53.9496498, 103.856247, 53.9496498])) > 1e-3).any()
     bler = float(hls_hat.any(1).float().mean())
     assert abs(bler - 396 / 5000) < 4 * np.sqrt(0.0792 * 0.9208 / 5000) * np.sqrt(2), bler
+
+
+def test_views_and_devices_are_handled_at_the_binding():
+    """graph.py passes raw pointers to the C ABI, so layout mistakes must be caught in Python: a correctly shaped but non-contiguous
+    READ-ONLY input is copied (same result as its contiguous twin), a non-contiguous IN-PLACE output is refused (a silent copy would
+    receive the result), wrong dtypes / shapes / devices raise ValueError, and a bare "cuda" device means torch's current device."""
+    from feedback_gnn_amd.graph import TannerGraph
+    c = code("gb48")
+    g = TannerGraph(c, device="cuda")
+    assert g.device == torch.device("cuda", torch.cuda.current_device())
+    ex, ez = g.pauli_noise(SEED, 0.08, 0, 64)
+    sx, sz = g.syndrome(ex, ez)
+    # non-contiguous read-only inputs: [n, B] tensors viewed as [B, n]
+    sx2, sz2 = g.syndrome(ex.t().contiguous().t(), ez.t().contiguous().t())
+    assert not ex.t().contiguous().t().is_contiguous() and torch.equal(sx, sx2) and torch.equal(sz, sz2)
+    o = g.bp4_decode(sx, sz, 8, "boxplus-phi", 0.8, llr_const=llr_const(0.1))
+    s1, l1, f1 = g.residual(ex, ez, o["x_hat"], o["z_hat"])
+    s2, l2, f2 = g.residual(ex.t().contiguous().t(), ez, o["x_hat"].t().contiguous().t(), o["z_hat"])
+    assert torch.equal(s1, s2) and torch.equal(l1, l2) and torch.equal(f1, f2)
+    # in-place outputs must be contiguous
+    errors = torch.ones(64, dtype=torch.uint8, device=g.device)
+    xh_view = o["x_hat"].t().contiguous().t()
+    with pytest.raises(ValueError, match="contiguous"):
+        g.merge(errors, o["x_hat"], o["z_hat"], xh_view, o["z_hat"].clone())
+    with pytest.raises(ValueError, match="contiguous"):
+        g.flag_update(o["x_hat"], o["z_hat"], sx, sz, torch.ones(128, dtype=torch.uint8, device=g.device)[::2])
+    g.merge(errors, o["x_hat"], o["z_hat"], o["x_hat"].clone(), o["z_hat"].clone())  # the contiguous call goes through
+    with pytest.raises(ValueError):
+        g.merge(errors.to(torch.int32), o["x_hat"], o["z_hat"], o["x_hat"].clone(), o["z_hat"].clone())  # dtype of `errors`
+    with pytest.raises(ValueError):
+        g.residual_rows(4, 5, ex[:, :-1], ez, o["x_hat"], o["z_hat"])  # shape
+    with pytest.raises(ValueError):
+        g.syndrome(ex.cpu(), ez.cpu())  # host tensors: wrong device, no CPU path
+    with pytest.raises(ValueError):
+        g.count_flags(f1, torch.zeros(3, dtype=torch.int32, device=g.device))
