@@ -37,7 +37,13 @@ def _worker(rank, world, port, q):
         model = _build_model(rank, world)
         F.sim_ber(model, [P], batch_size=BATCH // world, max_mc_iter=ITERS, verbose=False, dist=True, early_stop=False)
         st = F.sim_ber.last
-        q.put((rank, int(st["flag_errors"][0]), int(st["block_errors"][0]), int(st["num_blocks"][0])))
+        # decisions of ALL ranks on every rank: HIP bit-pack kernel -> all-gather (through host memory on gloo) -> unpack kernel
+        model2 = _build_model(rank, world)
+        d = model2.decode(BATCH // world, P)
+        xa, za = F.gather_decisions(d["x_hat"], d["z_hat"])
+        import hashlib
+        digest = hashlib.sha256(xa.cpu().numpy().tobytes() + za.cpu().numpy().tobytes()).hexdigest()
+        q.put((rank, int(st["flag_errors"][0]), int(st["block_errors"][0]), int(st["num_blocks"][0]), tuple(xa.shape), digest))
     finally:
         dist.destroy_process_group()
 
@@ -61,5 +67,9 @@ def test_two_rank_sim_ber_matches_single_process():
     st = F.sim_ber.last
     ref = (int(st["flag_errors"][0]), int(st["block_errors"][0]), int(st["num_blocks"][0]))
     assert ref[1] > 0 and ref[2] == BATCH * ITERS
-    for rank, fl, bl, nb in results:
+    import hashlib
+    d = _build_model(0, 1).decode(BATCH, P)  # the same first BATCH global samples in one piece
+    want = hashlib.sha256(d["x_hat"].cpu().numpy().tobytes() + d["z_hat"].cpu().numpy().tobytes()).hexdigest()
+    for rank, fl, bl, nb, shape, digest in results:
         assert (fl, bl, nb) == ref, (rank, fl, bl, nb, ref)
+        assert shape == (BATCH, 882) and digest == want, (rank, shape)
