@@ -106,14 +106,36 @@ def launch_ranks(args, argv):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     child_argv = [a for a in argv if a != "--no-build"] + ["--no-build"]
+    import tempfile
+    import time as _time
     procs = []
+    out0_file = tempfile.TemporaryFile(mode="w+")
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + child_argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+                                      stdout=out0_file if r == 0 else subprocess.DEVNULL))
+    # wait for all ranks; if one dies, the others would sit in a collective until its timeout: end them (exact PIDs) instead
+    codes = [None] * args.gpus
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+            break
+        _time.sleep(0.1)
+    out0_file.seek(0)
+    out0 = out0_file.read()
     # rank 0's stdout carries the ONE JSON line; anything else a library printed there (gloo's rendezvous banner) goes to stderr
     for line in out0.splitlines():
         is_json = line.lstrip().startswith("{") and line.rstrip().endswith("}")

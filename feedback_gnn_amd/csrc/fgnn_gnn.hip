@@ -115,8 +115,16 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_a
 
 // CPB codewords per workgroup, four waves each: the 34 KB of operand tables are shared, so LDS no longer caps the CU at four
 // workgroups of four waves — with CPB = 4 two 16-wave workgroups fill all 8 wave slots of every SIMD.
+#ifndef FGNN_GNN_CPB
+#define FGNN_GNN_CPB 4
+#endif
+#ifdef FGNN_GNN_WAVES
+#define FGNN_GNN_OCC __attribute__((amdgpu_waves_per_eu(FGNN_GNN_WAVES, FGNN_GNN_WAVES)))
+#else
+#define FGNN_GNN_OCC
+#endif
 template <int DV, int CPB>
-__global__ void __launch_bounds__(256 * CPB) gnn_mfma_kernel(GraphDev g, WeightsDev w, GnnArgs a)
+__global__ void __launch_bounds__(256 * CPB) FGNN_GNN_OCC gnn_mfma_kernel(GraphDev g, WeightsDev w, GnnArgs a)
 {
     extern __shared__ float lds[];
     const int cwl = threadIdx.x >> 8, tid = threadIdx.x & 255;
@@ -591,7 +599,7 @@ int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const flo
     }
     if (g->d.dvx == 3 && g->d.dvz == 3 && !g->force_generic) {
         // degree-regular graph: MFMA kernel, four waves per codeword, GNN_CPB codewords per workgroup
-        constexpr int GNN_CPB = 4;
+        constexpr int GNN_CPB = FGNN_GNN_CPB;
         // few codewords (a compacted feedback round at low p): one codeword's 56 tiles on four waves is 0.33 ms of latency on an
         // otherwise idle chip; dealt to up to 14 wave-quads it is one tile per wave
         const int ntiles = (g->d.n + 15) / 16;
