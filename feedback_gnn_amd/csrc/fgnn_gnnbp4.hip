@@ -282,14 +282,19 @@ __global__ void __launch_bounds__(256) gnn_bp4_kernel(GraphDev g, GnnBp4Dev w, A
 }
 
 template <int DV, int DC>
-__global__ void __launch_bounds__(512, 2) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4Dev w, Args a, int tab_floats)
+#ifndef FGNN_GNNBP4_THREADS
+#define FGNN_GNNBP4_THREADS 768  // threads per workgroup (= codeword) of the MFMA kernel; two workgroups share a CU: 6 waves per SIMD
+#endif
+__global__ void __launch_bounds__(FGNN_GNNBP4_THREADS, 2 * FGNN_GNNBP4_THREADS / 256)
+gnn_bp4_mfma_kernel(GraphDev g, GnnBp4Dev w, Args a, int tab_floats)
 {
     FG_LOG_TAB_SETUP();
     // LDS: [tab_floats] the current phase's per-lane operand tables (staged from L2 at every phase start: operand
     // reads then cost an LDS access instead of an L2 round trip, which is what the waves were waiting on), then
     // lx | lz | hlog.  512 threads = 8 waves share the staged tables; two workgroups fit a CU.
     extern __shared__ float lds[];
-    const int b = blockIdx.x, tid = threadIdx.x, T = 512, NW = 8;
+    constexpr int T = FGNN_GNNBP4_THREADS, NW = T / 64;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int n = g.n, mx = g.m_x, mz = g.m_z, m = g.m;
     float* tabs = lds;
     float* lx = lds + tab_floats;
@@ -327,15 +332,15 @@ __global__ void __launch_bounds__(512, 2) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4
                 load_row5(hv + (size_t)v * D, q, own);
                 // all 2 x DV neighbour rows of the tile are requested before the first MLP starts: the gathers (L2-resident rows of
                 // other workgroups' making) then complete under ~1 600 cycles of MFMA work each instead of in front of it
+                // neighbour rows one edge ahead: while the MLP of edge e runs (~1 600 cycles of MFMA work) the gather of edge e + 1
+                // (an L2-resident row of another workgroup's making) is in flight; all 2 x DV check ids are read up front
                 int cn_of[2][DV];
-                float fnb[2][DV][5];
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int k = 0; k < DV; ++k) {
-                        cn_of[s2][k] = g.vchk[(s2 ? g.E_x : 0) + v * DV + k];
-                        load_row5(hc + (size_t)((s2 ? mx : 0) + cn_of[s2][k]) * D, q, fnb[s2][k]);
-                    }
+                    for (int k = 0; k < DV; ++k) cn_of[s2][k] = g.vchk[(s2 ? g.E_x : 0) + v * DV + k];
+                float fcur[5], fnxt[5];
+                load_row5(hc + (size_t)cn_of[0][0] * D, q, fcur);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     float acc[5];
@@ -343,8 +348,14 @@ __global__ void __launch_bounds__(512, 2) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4
                     for (int k = 0; k < DV; ++k) {
                         const int c = cn_of[s2][k];
                         float Bin[10], msg[5];
+                        {
+                            const int e1 = s2 * DV + k + 1;  // next edge, flattened over both sides
+                            if (e1 < 2 * DV) load_row5(hc + (size_t)((e1 / DV ? mx : 0) + cn_of[e1 / DV][e1 % DV]) * D, q, fnxt);
+                        }
 #pragma unroll
-                        for (int s = 0; s < 5; ++s) { Bin[s] = fnb[s2][k][s]; Bin[5 + s] = own[s]; }
+                        for (int s = 0; s < 5; ++s) { Bin[s] = fcur[s]; Bin[5 + s] = own[s]; }
+#pragma unroll
+                        for (int s = 0; s < 5; ++s) fcur[s] = fnxt[s];
                         mlp_tile<10>(tab, w.tab_vn_msg[s2] - vn_first, Bin, msg);
                         const float sg = ssg[(s2 ? mx : 0) + c];
 #pragma unroll
@@ -407,14 +418,19 @@ __global__ void __launch_bounds__(512, 2) gnn_bp4_mfma_kernel(GraphDev g, GnnBp4
             const int c = (s2 ? mx : 0) + (valid ? local : cnt - 1);  // combined check id
             float own[5], acc[5], Bemb[11];
             load_row5(hc + (size_t)c * D, q, own);
-            float fnb[DC][5];  // the DC neighbour rows, requested up front (see the qubit phase)
+            int vn_of[DC];
 #pragma unroll
-            for (int k = 0; k < DC; ++k) load_row5(hv + (size_t)g.cvn[c * DC + k] * D, q, fnb[k]);
+            for (int k = 0; k < DC; ++k) vn_of[k] = g.cvn[c * DC + k];
+            float fcur[5], fnxt[5];  // neighbour rows one edge ahead (see the qubit phase)
+            load_row5(hv + (size_t)vn_of[0] * D, q, fcur);
 #pragma unroll
             for (int k = 0; k < DC; ++k) {
                 float Bin[10], msg[5];
+                if (k + 1 < DC) load_row5(hv + (size_t)vn_of[k + 1] * D, q, fnxt);
 #pragma unroll
-                for (int s = 0; s < 5; ++s) { Bin[s] = fnb[k][s]; Bin[5 + s] = own[s]; }
+                for (int s = 0; s < 5; ++s) { Bin[s] = fcur[s]; Bin[5 + s] = own[s]; }
+#pragma unroll
+                for (int s = 0; s < 5; ++s) fcur[s] = fnxt[s];
                 mlp_tile<10>(tab, w.tab_cn_msg[s2] - cn_first, Bin, msg);
 #pragma unroll
                 for (int i = 0; i < 5; ++i) acc[i] = (k == 0) ? msg[i] : acc[i] + msg[i];
@@ -611,7 +627,7 @@ extern "C" int fgnn_gnnbp4_decode(const fgnn_graph* g, const fgnn_gnnbp4_weights
         auto kern = gnn_bp4_mfma_kernel<3, 6>;
         if (lds2 > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "code too large for the GNN_BP4 MFMA kernel");
         FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds2, static_cast<hipStream_t>(stream), g->d, w->d, a, tab_floats);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(FGNN_GNNBP4_THREADS), lds2, static_cast<hipStream_t>(stream), g->d, w->d, a, tab_floats);
         FGNN_HIP_CHECK(hipGetLastError());
         return FGNN_OK;
     }
