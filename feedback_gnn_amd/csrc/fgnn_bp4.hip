@@ -7,8 +7,8 @@
 // then the marginals (:777), cal_logit (:455-471) and the hard decision (:783-790).
 //
 // The reference streams every [E,bs] message tensor through HBM ~10 times per half-iteration.
-// Here a codeword's state (E floats of messages + 3n channel LLRs, 32 KB for [[882,24]]) never
-// leaves the CU: HBM sees the syndromes once and the results once.  The kernel is therefore bound
+// Here a codeword's state (E floats of messages, 21 KB for [[882,24]], in LDS; per-qubit channel LLRs in registers for the
+// benchmark codes, else 3n more floats of LDS) never leaves the CU: HBM sees the syndromes once and the results once.  The kernel is therefore bound
 // by VALU issue (about 830 fma-class ops per qubit-iteration for the exact exp/log of
 // fgnn_math.h), not by HBM; DESIGN.md §4 gives the accounting next to the streaming-model figure.
 //
