@@ -144,8 +144,8 @@ def test_second_stage_value_and_grad_matches_float64_autograd():
 def test_value_and_grad_matches_finite_differences_of_the_gpu_forward():
     """A check of the hand-written reverse pass that involves NO restatement: central differences of the HIP forward's own loss
     (Second_Stage_GNN_BP_Model.__call__: GNN -> stage_two BP -> BCE) along random directions in weight space, against the
-    directional derivative <grad, direction> from value_and_grad (three full-space directions, then W1 of the hx-edge MLP, its
-    bias, and the node-embedding kernel alone).  Measured agreement: 3e-4 of the gradient scale; the bar is 5e-3."""
+    directional derivative <grad, direction> from value_and_grad (three full-space directions, then the output kernel, the first bias
+    of the hx-edge MLP and the node-embedding kernel alone).  Measured agreement: 3e-4 of the gradient scale; the bar is 5e-3."""
     from feedback_gnn_amd import QLDPCBPDecoder, Feedback_GNN, First_Stage_BP_Model, Second_Stage_GNN_BP_Model, load_weights
     name, B = "ghp882", 16
     c = code(name)
