@@ -2,7 +2,8 @@
 examples/Generate_dataset.ipynb (easy set = BP failures on fixed-weight errors; coarse GNN; hard set = failures of
 BP64 -> GNN -> BP64; mixed set with the hard samples repeated 50x) and examples/Feedback_GNN.ipynb cell 8 (one epoch,
 batch 100, Adam 2e-4, clip 10).  Sample counts are scaled by `scale` (1.0 = the notebook's counts).
-usage: python tools/train_full_recipe.py [scale=0.2] [eval_samples=300000]
+usage: python tools/train_full_recipe.py [scale=0.2] [eval_samples=300000] [hard_scale=scale]
+`hard_scale` scales the hard-sample mining alone (the authors collected their ~11 k hard samples over repeated runs of that cell).
 """
 import json, os, sys, time
 import numpy as np, torch
@@ -15,6 +16,7 @@ from feedback_gnn_amd.weights_io import write_weight_list
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.2
 eval_samples = int(sys.argv[2]) if len(sys.argv) > 2 else 300000
+hard_scale = float(sys.argv[3]) if len(sys.argv) > 3 else scale
 c = get_code("ghp882")
 mk = lambda it, **kw: QLDPCBPDecoder(code=c, num_iter=it, normalization_factor=1.0, cn_type="boxplus-phi", **kw)  # noqa: E731
 dec64 = mk(64, stage_one=True)
@@ -64,7 +66,7 @@ Gc = newG()
 train(Gc, dec16, Xe1, Ze1, "coarse")
 
 # 3. hard sets (cells 8, 15): failures of BP64 -> coarse GNN -> BP64, 200 x 5000 samples per weight
-it_hard = max(1, int(round(200 * scale)))
+it_hard = max(1, int(round(200 * hard_scale)))
 t0 = time.time()
 two_stage = Sandwich_BP_GNN_Evaluation_Model(c, [dec64, dec64], [Gc], num_layers=2, wt=True)
 Xh, Zh, dh = collect(two_stage, range(4, 61), 5000, it_hard)
@@ -94,6 +96,7 @@ for p in (0.10, 0.08):
         print(f"p={p:.2f} {tag:14s} flagged {fl:6d}  logical {bl:6d} / {tot}  BLER {bl/tot:.5f}", flush=True)
 log["eval"] = res
 log["scale"] = scale
+log["hard_scale"] = hard_scale
 log["total_seconds"] = time.time() - T0
 json.dump(log, open("gpurun_out/train_full_ghp882.json", "w"), indent=1)
 print(f"total {time.time()-T0:.1f}s")
