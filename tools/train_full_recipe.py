@@ -2,8 +2,11 @@
 examples/Generate_dataset.ipynb (easy set = BP failures on fixed-weight errors; coarse GNN; hard set = failures of
 BP64 -> GNN -> BP64; mixed set with the hard samples repeated 50x) and examples/Feedback_GNN.ipynb cell 8 (one epoch,
 batch 100, Adam 2e-4, clip 10).  Sample counts are scaled by `scale` (1.0 = the notebook's counts).
-usage: python tools/train_full_recipe.py [scale=0.2] [eval_samples=300000] [hard_scale=scale]
-`hard_scale` scales the hard-sample mining alone (the authors collected their ~11 k hard samples over repeated runs of that cell).
+usage: python tools/train_full_recipe.py [scale=0.2] [eval_samples=300000] [hard_scale=scale] [easy_scale=scale] [quirk=0]
+`hard_scale` scales the hard-sample mining alone (the authors collected their ~11 k hard samples over repeated runs of that cell),
+`easy_scale` the easy set of weights 4-40 (theirs holds 439 916 samples = 1.76 passes of cell 5).  `quirk=1` reproduces what
+Generate_dataset.ipynb cell 16 actually assembles for [[882,24]]: the z part of the weight-41..60 hard samples is loaded from the
+*x* file (`dz_41_60_hard = np.load(".._x_hard.npy")`), i.e. those samples enter training with z = x.
 """
 import json, os, sys, time
 import numpy as np, torch
@@ -17,6 +20,8 @@ from feedback_gnn_amd.weights_io import write_weight_list
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.2
 eval_samples = int(sys.argv[2]) if len(sys.argv) > 2 else 300000
 hard_scale = float(sys.argv[3]) if len(sys.argv) > 3 else scale
+easy_scale = float(sys.argv[4]) if len(sys.argv) > 4 else scale
+quirk = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 c = get_code("ghp882")
 mk = lambda it, **kw: QLDPCBPDecoder(code=c, num_iter=it, normalization_factor=1.0, cn_type="boxplus-phi", **kw)  # noqa: E731
 dec64 = mk(64, stage_one=True)
@@ -53,7 +58,7 @@ def train(G, dec_first, X, Z, tag):
 it_easy = max(1, int(round(50 * scale)))
 t0 = time.time()
 bp_only = Sandwich_BP_GNN_Evaluation_Model(c, [dec64], [], num_layers=1, wt=True)
-Xe1, Ze1, d1 = collect(bp_only, range(4, 41), 50000, it_easy)
+Xe1, Ze1, d1 = collect(bp_only, range(4, 41), 50000, max(1, int(round(50 * easy_scale))))
 Xe2, Ze2, d2 = collect(bp_only, range(41, 61), 50000, it_easy)
 n2 = min(int(Xe2.shape[0]), int(300000 * scale))
 sel = torch.randperm(int(Xe2.shape[0]), device=g.device)[:n2]
@@ -70,7 +75,11 @@ it_hard = max(1, int(round(200 * hard_scale)))
 t0 = time.time()
 two_stage = Sandwich_BP_GNN_Evaluation_Model(c, [dec64, dec64], [Gc], num_layers=2, wt=True)
 Xh, Zh, dh = collect(two_stage, range(4, 61), 5000, it_hard)
-log["hard"] = dict(drawn=dh, found=int(Xh.shape[0]), seconds=time.time() - t0)
+if quirk:  # cell 16 of Generate_dataset.ipynb: z of the weight 41..60 hard samples := their x
+    wt_h = (Xh | Zh).sum(1)
+    hi = wt_h >= 41
+    Zh = torch.where(hi[:, None], Xh, Zh)
+log["hard"] = dict(drawn=dh, found=int(Xh.shape[0]), seconds=time.time() - t0, quirk=quirk)
 print(f"[hard] {Xh.shape[0]} two-stage failures from {dh} samples in {time.time()-t0:.1f}s", flush=True)
 
 # 4. mixed set (cell 16): easy + hard x 50, then one epoch from a fresh GNN with the 64/16 pipeline
@@ -97,6 +106,7 @@ for p in (0.10, 0.08):
 log["eval"] = res
 log["scale"] = scale
 log["hard_scale"] = hard_scale
+log["easy_scale"] = easy_scale
 log["total_seconds"] = time.time() - T0
 json.dump(log, open("gpurun_out/train_full_ghp882.json", "w"), indent=1)
 print(f"total {time.time()-T0:.1f}s")
