@@ -259,7 +259,13 @@ __device__ __forceinline__ void phi_n(const float (&x)[N], float (&out)[N])
 // configurations without the LDS round trip of the runtime-degree version.  Same float ops, same order.
 // Signs are carried as integer sign words: neg = (synd << 31) ^ bits(v_0) ^ ... (bit 31 = the parity of :398-399), and the
 // outgoing sign of edge j is bit 31 of neg ^ bits(v_j) — one xor per edge in, one xor + one bit-field insert per edge out.
-template <int DC, bool HWT = false>
+// `sl` = BYTE offsets of the check's slots from `msg` (the packed rows of g.cslot16 hold 4 * slot); F1 = the normalisation factor is
+// exactly 1 (feedback_gnn.py / n882.py: every paper run), so the product with it — the identity on every float — is not issued.
+__device__ __forceinline__ float& slot_ref(float* msg, int byte_off)
+{
+    return *reinterpret_cast<float*>(reinterpret_cast<char*>(msg) + byte_off);
+}
+template <int DC, bool HWT = false, bool F1 = false>
 __device__ __forceinline__ bool cn_phi_regular(float* msg, const int (&sl)[DC], unsigned synd, float factor, float phi0,
                                                bool shortcut)
 {
@@ -270,7 +276,7 @@ __device__ __forceinline__ bool cn_phi_regular(float* msg, const int (&sl)[DC], 
     bool sat = true;
 #pragma unroll
     for (int j = 0; j < DC; ++j) {
-        v[j] = msg[sl[j]];
+        v[j] = slot_ref(msg, sl[j]);
         neg ^= fg_f2u(v[j]);
         sat = sat && (FG_ABS(v[j]) >= FG_PHI_MAX);
     }
@@ -279,7 +285,10 @@ __device__ __forceinline__ bool cn_phi_regular(float* msg, const int (&sl)[DC], 
     // lanes of the wave are saturated (one v_cmp + s_cbranch), which is the steady state of a converged codeword.
     if (shortcut && __all(sat)) {
 #pragma unroll
-        for (int j = 0; j < DC; ++j) msg[sl[j]] = fg_u2f(fg_f2u(phi0) | ((neg ^ fg_f2u(v[j])) & 0x80000000u)) * factor;
+        for (int j = 0; j < DC; ++j) {
+            const float o = fg_u2f(fg_f2u(phi0) | ((neg ^ fg_f2u(v[j])) & 0x80000000u));
+            slot_ref(msg, sl[j]) = F1 ? o : o * factor;
+        }
         return true;
     }
 #pragma unroll
@@ -301,8 +310,10 @@ __device__ __forceinline__ bool cn_phi_regular(float* msg, const int (&sl)[DC], 
         for (int j = 0; j < H; ++j) xa[j] = T - aa[g0 + j];
         phi_n<H, HWT>(xa, oa);
 #pragma unroll
-        for (int j = 0; j < H; ++j)
-            msg[sl[g0 + j]] = fg_u2f(fg_f2u(oa[j]) | ((neg ^ fg_f2u(v[g0 + j])) & 0x80000000u)) * factor;
+        for (int j = 0; j < H; ++j) {
+            const float o = fg_u2f(fg_f2u(oa[j]) | ((neg ^ fg_f2u(v[g0 + j])) & 0x80000000u));
+            slot_ref(msg, sl[g0 + j]) = F1 ? o : o * factor;
+        }
     }
     return false;
 }
@@ -438,13 +449,14 @@ bp4_kernel(GraphDev g, BpArgs a)
                     }
                     const float val = with_sign(MX::phi(T - aa), neg ^ ng) * a.factor;
 #pragma unroll
-                    for (int j = 0; j < DC; ++j) msg[(int)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu)] = val;
+                    for (int j = 0; j < DC; ++j) slot_ref(msg, (int)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu)) = val;
                 }
             a1 = FG_ABS(nu_x) >= FG_PHI_MAX && FG_ABS(nu_z) >= FG_PHI_MAX;  // "iteration 0's check phase was all-saturated"
             it_begin = 1;
             __syncthreads();
         }
     }
+    const bool cn_one = a.cpb == 1, cn_f1 = a.factor == 1.0f;  // workgroup-uniform: which copy of the regular phi update runs
     for (int it = it_begin; it < a.num_iter; ++it) {
         bool changed = false, cn_slow = false;
         // ---- variable nodes: _vn_update (:227-275) ----
@@ -589,12 +601,22 @@ bp4_kernel(GraphDev g, BpArgs a)
                 if constexpr (REGULAR) {
                     const uint4 pk = reinterpret_cast<const uint4*>(g.cslot16)[c];
                     const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
-                    int sl[DC];
+                    int sl[DC];  // byte offsets
 #pragma unroll
                     for (int j = 0; j < DC; ++j) sl[j] = (int)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
-                    if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI)
-                        cn_slow = !cn_phi_regular<DC, HWT>(msg, sl, synd, a.factor, phi0, opt_shortcut) || cn_slow;
-                    else cn_update<CN_TYPE, HWT>(msg, sl, DC, synd, a.factor);
+                    if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI) {
+                        // one codeword per workgroup: the message area starts at the (compile-time) base of the dynamic LDS, so the
+                        // byte offsets are the LDS addresses up to an immediate; factor 1: no product
+                        bool fast;
+                        if (cn_one && cn_f1) fast = cn_phi_regular<DC, HWT, true>(lds, sl, synd, 1.0f, phi0, opt_shortcut);
+                        else if (cn_one) fast = cn_phi_regular<DC, HWT, false>(lds, sl, synd, a.factor, phi0, opt_shortcut);
+                        else fast = cn_phi_regular<DC, HWT, false>(msg, sl, synd, a.factor, phi0, opt_shortcut);
+                        cn_slow = !fast || cn_slow;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) sl[j] >>= 2;
+                        cn_update<CN_TYPE, HWT>(msg, sl, DC, synd, a.factor);
+                    }
                 } else {
                     const int c0 = g.cptr[c], deg = g.cptr[c + 1] - c0;
                     if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI)

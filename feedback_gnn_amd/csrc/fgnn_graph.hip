@@ -172,10 +172,11 @@ extern "C" int fgnn_graph_create(int n, int m_x, int m_z, int nnz_x, const int32
     for (int v = 0; v < n; ++v)
         d.max_vdeg = std::max(d.max_vdeg, (vptr[0][v + 1] - vptr[0][v]) + (vptr[1][v + 1] - vptr[1][v]));
     int rc;
-    if (d.dvx > 0 && d.dvz > 0 && d.dc > 0 && d.dc <= 8 && d.E < 65536) {
+    if (d.dvx > 0 && d.dvz > 0 && d.dc > 0 && d.dc <= 8 && (long long)d.E * 4 < 65536) {
+        // BYTE offsets of the slots (slot * 4): a check's LDS addresses are then one mask / shift away from the packed row
         std::vector<uint16_t> pk((size_t)d.m * 8, 0);
         for (int c = 0; c < d.m; ++c)
-            for (int j = 0; j < d.dc; ++j) pk[(size_t)c * 8 + j] = (uint16_t)cslot[cptr[c] + j];
+            for (int j = 0; j < d.dc; ++j) pk[(size_t)c * 8 + j] = (uint16_t)(4 * cslot[cptr[c] + j]);
         if ((rc = upload(g, pk, &d.cslot16))) {
             fgnn_graph_destroy(g);
             return rc;

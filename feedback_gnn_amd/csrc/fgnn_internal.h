@@ -18,7 +18,7 @@ struct GraphDev {
     const int* cptr;    // [m+1] combined checks: hx rows 0..m_x-1 then hz rows; offsets into cslot/cvn
     const int* cslot;   // [E]   message slot of the k-th edge of a check (ascending qubit)
     const int* cvn;     // [E]   qubit of that edge
-    const uint16_t* cslot16;  // [m][8] packed slot rows for DC-regular graphs with DC <= 8 and E < 65536, else null
+    const uint16_t* cslot16;  // [m][8] packed rows of slot BYTE offsets (4 * slot) for DC-regular graphs with DC <= 8 and 4E < 65536, else null
     // CSR row sets (fgnn_graph_set_rows)
     int rows[6];
     const int* rptr[6];
