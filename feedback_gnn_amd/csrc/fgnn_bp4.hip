@@ -457,6 +457,13 @@ bp4_kernel(GraphDev g, BpArgs a)
         }
     }
     const bool cn_one = a.cpb == 1, cn_f1 = a.factor == 1.0f;  // workgroup-uniform: which copy of the regular phi update runs
+    // the syndrome bits of this thread's checks (lane_c, lane_c + tpc, ...) as one register: read once, not once per iteration
+    unsigned synd_bits = 0;
+    if (active) {
+        int i = 0;
+        for (int c = lane_c; c < g.m && i < 32; c += a.tpc, ++i) synd_bits |= ((c < g.m_x ? sx[c] : sz[c - g.m_x]) & 1u) << i;
+    }
+    const bool synd_in_reg = (g.m + a.tpc - 1) / a.tpc <= 32;
     for (int it = it_begin; it < a.num_iter; ++it) {
         bool changed = false, cn_slow = false;
         // ---- variable nodes: _vn_update (:227-275) ----
@@ -595,9 +602,10 @@ bp4_kernel(GraphDev g, BpArgs a)
         }
         // checks are dealt to the threads half a workgroup out of phase with the qubits: with 882 nodes on 4 waves two waves get
         // 4 slices of 64 and two get 3 — the qubit phase gives the extra slice to the low waves, the check phase to the high ones
-        if (active)
-            for (int c = lane_c; c < g.m; c += a.tpc) {
-                const unsigned synd = (c < g.m_x ? sx[c] : sz[c - g.m_x]) & 1u;
+        if (active) {
+            int ci = 0;
+            for (int c = lane_c; c < g.m; c += a.tpc, ++ci) {
+                const unsigned synd = synd_in_reg ? (synd_bits >> ci) & 1u : (c < g.m_x ? sx[c] : sz[c - g.m_x]) & 1u;
                 if constexpr (REGULAR) {
                     const uint4 pk = reinterpret_cast<const uint4*>(g.cslot16)[c];
                     const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
@@ -624,6 +632,7 @@ bp4_kernel(GraphDev g, BpArgs a)
                     else cn_update<CN_TYPE, HWT>(msg, g.cslot + c0, deg, synd, a.factor);
                 }
             }
+        }
         if (opt_exit && cn_slow) flags[2 * (it & 1) + 1] = 1;
         __syncthreads();
         if (opt_exit) {
