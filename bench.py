@@ -90,7 +90,6 @@ def launch_ranks(args, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher: start N ranks (one process per GPU, the way the reference
     pins one process per GPU id, /root/reference n882.py:9,15-21) and relay rank 0's JSON line.  This parent never touches a
     GPU: torch.cuda.device_count() does not initialise one, and the children are fresh interpreters."""
-    import socket
     import subprocess
     import torch
     backend = os.environ.get("FGNN_BENCH_BACKEND", "nccl")
@@ -102,40 +101,9 @@ def launch_ranks(args, argv):
         rc = subprocess.call([sys.executable, "-c", "import __graft_entry__ as e; e.build()"], cwd=ROOT)
         if rc != 0:
             raise SystemExit("bench.py: build failed")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    from feedback_gnn_amd.launch import spawn_ranks  # host-only module: no GPU library is loaded in this parent
     child_argv = [a for a in argv if a != "--no-build"] + ["--no-build"]
-    import tempfile
-    import time as _time
-    procs = []
-    out0_file = tempfile.TemporaryFile(mode="w+")
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + child_argv, env=env,
-                                      stdout=out0_file if r == 0 else subprocess.DEVNULL))
-    # wait for all ranks; if one dies, the others would sit in a collective until its timeout: end them (exact PIDs) instead
-    codes = [None] * args.gpus
-    while any(c is None for c in codes):
-        for r, p in enumerate(procs):
-            if codes[r] is None:
-                codes[r] = p.poll()
-        if any(c not in (None, 0) for c in codes):
-            for r, p in enumerate(procs):
-                if codes[r] is None:
-                    p.terminate()
-            for r, p in enumerate(procs):
-                if codes[r] is None:
-                    try:
-                        codes[r] = p.wait(timeout=20)
-                    except subprocess.TimeoutExpired:
-                        p.kill()
-                        codes[r] = p.wait()
-            break
-        _time.sleep(0.1)
-    out0_file.seek(0)
-    out0 = out0_file.read()
+    codes, out0 = spawn_ranks(__file__, child_argv, args.gpus, capture_rank0=True)
     # rank 0's stdout carries the ONE JSON line; anything else a library printed there (gloo's rendezvous banner) goes to stderr
     for line in out0.splitlines():
         is_json = line.lstrip().startswith("{") and line.rstrip().endswith("}")

@@ -3,7 +3,8 @@
 do in the reference (n882.py:27-78, n1270.py:27-81), for either benchmark code.
 
     python examples/evaluate.py --code ghp882 -nG 5 -p 0.05 -id 0
-    torchrun --nproc-per-node 8 examples/evaluate.py --code ghp1270 -nG 3 -p 0.06 --dist     # one rank per GPU, counters all-reduced
+    python examples/evaluate.py --code ghp1270 -nG 3 -p 0.06 --gpus 8                          # starts 8 ranks itself, one per GPU
+    torchrun --nproc-per-node 8 examples/evaluate.py --code ghp1270 -nG 3 -p 0.06 --dist     # the same under a launcher
 
 Prints the reference's result table (p | Flagged | BLER | flag errors | block errors | num blocks | runtime | status).
 """
@@ -26,7 +27,16 @@ def main():
     ap.add_argument("--target", type=int, default=100, help="stop a point after this many logical errors")
     ap.add_argument("--max-iter", type=int, default=100000)
     ap.add_argument("--dist", action="store_true", help="one process per GPU under torchrun; sample stream sharded by rank")
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1 without a launcher: start N ranks (one per GPU) and run --dist in each")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # parent: never touches a GPU (device_count() does not initialise one); the ranks are fresh interpreters
+        from feedback_gnn_amd.launch import spawn_ranks, visible_gpus
+        if visible_gpus() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {visible_gpus()} GPU(s) are visible")
+        codes, _ = spawn_ranks(__file__, [a for a in sys.argv[1:] if a != "--dist"] + ["--dist"], args.gpus)
+        raise SystemExit(max(abs(c) for c in codes))
 
     import torch
     rank, world = 0, 1
