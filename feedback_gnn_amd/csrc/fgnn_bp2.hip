@@ -13,6 +13,13 @@
 #include "fgnn_math.h"
 #include "fgnn_rng.h"
 
+#ifndef FGNN_BP2_WAVES
+#define FGNN_BP2_WAVES 6  // waves per SIMD the register allocation aims at
+#endif
+#ifndef FGNN_BP2_PHI_STAGE
+#define FGNN_BP2_PHI_STAGE 2  // phi evaluations staged together in the regular check update, must divide DC
+#endif
+
 namespace {
 
 struct Bp2Args {
@@ -99,10 +106,95 @@ __device__ __forceinline__ void cn_update2(float* msg, const int* __restrict__ s
     }
 }
 
-template <int CN_TYPE>
-__global__ void __launch_bounds__(1024) bp2_kernel(GraphDev g, Bp2Args a)
+// N evaluations of fg_phi_gnn with the table reads of all 2N logarithms in flight together: the float operations of
+// fg_phi_gnn (fg_exp, then fg_log(y + 1) - fg_log(y - 1)) in the same order, only the instruction schedule differs.
+template <int N>
+__device__ __forceinline__ void phi_gnn_n(const float (&x)[N], float (&out)[N])
+{
+    const float* tab = fg_log_tab();
+    float yp[N], ym[N];
+    uint32_t eb1[N], eb2[N], j1[N], j2[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float y = fg_exp(FG_CLAMP(x[k], FG_PHI_MIN, FG_PHI_MAX));
+        yp[k] = y + 1.0f;
+        ym[k] = y - 1.0f;
+        const uint32_t w1 = fg_f2u(yp[k]) - FG_LOG_OFFS;
+        const uint32_t w2 = fg_f2u(ym[k]) - FG_LOG_OFFS;
+        eb1[k] = w1 & 0xff800000u;
+        eb2[k] = w2 & 0xff800000u;
+        j1[k] = (w1 >> 18) & 31u;
+        j2[k] = (w2 >> 18) & 31u;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float rc1[N], lc1[N], rc2[N], lc2[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        rc1[k] = tab[j1[k]];
+        lc1[k] = tab[32 + j1[k]];
+        rc2[k] = tab[j2[k]];
+        lc2[k] = tab[32 + j2[k]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float r1 = FG_FMA(fg_u2f(fg_f2u(yp[k]) - eb1[k]), rc1[k], -1.0f);
+        const float l1 = FG_FMA((float)(int32_t)eb1[k], FG_LN2_S23, lc1[k] + fg_log1p_small(r1));
+        const float r2 = FG_FMA(fg_u2f(fg_f2u(ym[k]) - eb2[k]), rc2[k], -1.0f);
+        const float l2 = FG_FMA((float)(int32_t)eb2[k], FG_LN2_S23, lc2[k] + fg_log1p_small(r2));
+        out[k] = l1 - l2;
+    }
+}
+
+// _cn_update_phi (decoding.py:637-693) for a check of compile-time degree DC: its DC messages are read once, live in registers
+// between the two phi passes (cn_update2 parks phi(|v|) in LDS and reads it back) and are written once; signs travel as bit 31
+// of integer words.  Same float operations in the same order as cn_update2<FGNN_CN_BOXPLUS_PHI>.
+template <int DC>
+__device__ __forceinline__ void cn2_phi_regular(float* msg, const unsigned (&off)[DC], unsigned synd, float factor, bool f1)
+{
+    float v[DC], aa[DC];
+    uint32_t neg = synd << 31;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        v[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(msg) + off[j]);
+        // cn_update2 tests v < 0: a message of -0 counts as positive there, and its parked copy carries no sign either
+        neg ^= (v[j] < 0.0f) ? 0x80000000u : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < DC; j += FGNN_BP2_PHI_STAGE) {
+        float xa[FGNN_BP2_PHI_STAGE], oa[FGNN_BP2_PHI_STAGE];
+#pragma unroll
+        for (int k = 0; k < FGNN_BP2_PHI_STAGE; ++k) xa[k] = FG_ABS(v[j + k]);
+        phi_gnn_n<FGNN_BP2_PHI_STAGE>(xa, oa);
+#pragma unroll
+        for (int k = 0; k < FGNN_BP2_PHI_STAGE; ++k) aa[j + k] = oa[k];
+    }
+    float T = 0.0f;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) T = T + aa[j];
+#pragma unroll
+    for (int j = 0; j < DC; j += FGNN_BP2_PHI_STAGE) {
+        float xa[FGNN_BP2_PHI_STAGE], oa[FGNN_BP2_PHI_STAGE];
+#pragma unroll
+        for (int k = 0; k < FGNN_BP2_PHI_STAGE; ++k) xa[k] = T - FG_ABS(aa[j + k]);
+        phi_gnn_n<FGNN_BP2_PHI_STAGE>(xa, oa);
+#pragma unroll
+        for (int k = 0; k < FGNN_BP2_PHI_STAGE; ++k) {
+            // sign of the parked word with_sign(phi(|v|), v < 0) that cn_update2 reads back
+            const uint32_t sg = neg ^ ((v[j + k] < 0.0f) ? 0x80000000u : 0u) ^ (fg_f2u(aa[j + k]) & 0x80000000u);
+            const float o = fg_u2f(fg_f2u(oa[k]) ^ sg);
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(msg) + off[j + k]) = f1 ? o : o * factor;
+        }
+    }
+}
+
+// DV/DC > 0 (phi rule only): every bit has DV edges at slots v*DV .. v*DV+DV-1 and every check DC edges whose slot byte offsets
+// come as one packed 16-byte row of g.cslot16 (the hx rows are the first m_x of it); DV = 0: runtime degrees through the CSR tables.
+template <int CN_TYPE, int DV, int DC>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FGNN_BP2_WAVES))) bp2_kernel(GraphDev g, Bp2Args a)
 {
     FG_LOG_TAB_SETUP();
+    constexpr bool REGULAR = DV > 0;
     extern __shared__ float lds[];
     const int cwl = threadIdx.x / a.tpc;
     const int lane = threadIdx.x - cwl * a.tpc;
@@ -112,6 +204,14 @@ __global__ void __launch_bounds__(1024) bp2_kernel(GraphDev g, Bp2Args a)
     const int n = g.n, m = g.m_x;
     if (active)
         for (int e = lane; e < g.E_x; e += a.tpc) msg[e] = 0.0f;
+    // the syndrome bits of the checks lane, lane + tpc, ... this thread owns, one register for all iterations
+    const bool synd_in_reg = (m + a.tpc - 1) / a.tpc <= 32;
+    unsigned synd_bits = 0;
+    if (active && a.synd && synd_in_reg) {
+        int k = 0;
+        for (int c = lane; c < m; c += a.tpc, ++k) synd_bits |= (unsigned)(a.synd[(size_t)b * m + c] & 1u) << k;
+    }
+    const bool f1 = a.factor == 1.0f;
     __syncthreads();
     for (int it = 0; it <= a.num_iter; ++it) {
         if (active)
@@ -119,26 +219,56 @@ __global__ void __launch_bounds__(1024) bp2_kernel(GraphDev g, Bp2Args a)
                 float lc = a.llr_ch ? a.llr_ch[(size_t)b * n + v] : a.llr_const;
                 lc = FG_MIN(FG_MAX(lc, -20.0f), 20.0f);
                 const float L = -1.0f * lc;
-                const int e0 = g.vptr_x[v], e1 = g.vptr_x[v + 1];
-                float S = 0.0f;
-                for (int e = e0; e < e1; ++e) S = S + msg[e];
-                if (it == a.num_iter) {
-                    const float o = -1.0f * (L + S);
-                    if (a.soft_out) a.soft_out[(size_t)b * n + v] = o;
-                    if (a.hard_out) a.hard_out[(size_t)b * n + v] = (uint8_t)(0.0f < o);
-                    continue;
+                if constexpr (REGULAR) {
+                    float* mv = msg + v * DV;
+                    float mi[DV];
+#pragma unroll
+                    for (int k = 0; k < DV; ++k) mi[k] = mv[k];
+                    float S = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < DV; ++k) S = S + mi[k];
+                    if (it == a.num_iter) {
+                        const float o = -1.0f * (L + S);
+                        if (a.soft_out) a.soft_out[(size_t)b * n + v] = o;
+                        if (a.hard_out) a.hard_out[(size_t)b * n + v] = (uint8_t)(0.0f < o);
+                        continue;
+                    }
+                    const float x = S + L;
+#pragma unroll
+                    for (int k = 0; k < DV; ++k) mv[k] = x - mi[k];
+                } else {
+                    const int e0 = g.vptr_x[v], e1 = g.vptr_x[v + 1];
+                    float S = 0.0f;
+                    for (int e = e0; e < e1; ++e) S = S + msg[e];
+                    if (it == a.num_iter) {
+                        const float o = -1.0f * (L + S);
+                        if (a.soft_out) a.soft_out[(size_t)b * n + v] = o;
+                        if (a.hard_out) a.hard_out[(size_t)b * n + v] = (uint8_t)(0.0f < o);
+                        continue;
+                    }
+                    const float x = S + L;
+                    for (int e = e0; e < e1; ++e) msg[e] = x - msg[e];
                 }
-                const float x = S + L;
-                for (int e = e0; e < e1; ++e) msg[e] = x - msg[e];
             }
         if (it == a.num_iter) break;
         __syncthreads();
-        if (active)
-            for (int c = lane; c < m; c += a.tpc) {
-                const int c0 = g.cptr[c], deg = g.cptr[c + 1] - c0;
-                const unsigned sy = a.synd ? (a.synd[(size_t)b * m + c] & 1u) : 0u;
-                cn_update2<CN_TYPE>(msg, g.cslot + c0, deg, sy, a.factor);
+        if (active) {
+            int k = 0;
+            for (int c = lane; c < m; c += a.tpc, ++k) {
+                const unsigned sy = !a.synd ? 0u : synd_in_reg ? ((synd_bits >> k) & 1u) : (a.synd[(size_t)b * m + c] & 1u);
+                if constexpr (REGULAR) {
+                    const uint4 pk = reinterpret_cast<const uint4*>(g.cslot16)[c];
+                    const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
+                    unsigned off[DC];
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) off[j] = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                    cn2_phi_regular<DC>(msg, off, sy, a.factor, f1);
+                } else {
+                    const int c0 = g.cptr[c], deg = g.cptr[c + 1] - c0;
+                    cn_update2<CN_TYPE>(msg, g.cslot + c0, deg, sy, a.factor);
+                }
             }
+        }
         __syncthreads();
     }
 }
@@ -156,10 +286,10 @@ __global__ void __launch_bounds__(256) bsc_kernel(uint64_t seed, float p, uint64
         if (blk * 4 + k < n) noise[(size_t)b * n + blk * 4 + k] = (uint8_t)(u[k] < p);
 }
 
-template <int CN_TYPE>
+template <int CN_TYPE, int DV = 0, int DC = 0>
 int launch(const fgnn_graph* g, const Bp2Args& a, const LaunchGeom& L, size_t lds_bytes, hipStream_t st)
 {
-    auto kern = bp2_kernel<CN_TYPE>;
+    auto kern = bp2_kernel<CN_TYPE, DV, DC>;
     if (lds_bytes > 48 * 1024)
         FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes));
@@ -195,6 +325,10 @@ extern "C" int fgnn_bp2_decode(const fgnn_graph* g, int cn_type, int num_iter, f
     const size_t lds_bytes = (size_t)a.lds_per_cw * sizeof(float) * (size_t)L.cpb;
     if (lds_bytes > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident kernel");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // the register-resident check update for (3,6)-regular hx graphs (the [[882,24]] family; cslot16 exists for check degrees up to 8;
+    // slots of side 0 come first in the combined numbering, so its byte offsets index this kernel's message area directly)
+    const bool regular = cn_type == FGNN_CN_BOXPLUS_PHI && g->d.cslot16 && !g->force_generic;
+    if (regular && g->d.dvx == 3 && g->d.dc == 6) return launch<FGNN_CN_BOXPLUS_PHI, 3, 6>(g, a, L, lds_bytes, st);
     switch (cn_type) {
     case FGNN_CN_BOXPLUS_PHI: return launch<FGNN_CN_BOXPLUS_PHI>(g, a, L, lds_bytes, st);
     case FGNN_CN_MINSUM: return launch<FGNN_CN_MINSUM>(g, a, L, lds_bytes, st);

@@ -1,12 +1,14 @@
 """Binary syndrome BP (LDPCBPDecoder(is_syndrome=True), /root/reference sionna/fec/ldpc/decoding.py) on the hx graph of [[882,24]]:
 kernel time at the reference's QLDPC.ipynb cell 7 setting (64 iterations, boxplus-phi) for 65 536 syndromes.   python tools/bench_bp2.py"""
-import sys, torch
+import os, sys, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from helpers import code
 from feedback_gnn_amd.graph import TannerGraph
 import numpy as np
 g = TannerGraph(code('ghp882'))
 B = 65536
+if os.environ.get('BP2_LAUNCH'):  # A/B of the launch geometry: BP2_LAUNCH=tpc,cpb
+    g.set_launch(*map(int, os.environ['BP2_LAUNCH'].split(',')))
 for p in (0.01, 0.05):
     e = g.bsc_noise(0x5EED, p, 0, B)
     sx, _ = g.syndrome(torch.zeros_like(e), e)
