@@ -283,15 +283,22 @@ __global__ void __launch_bounds__(256) gnn_bp4_kernel(GraphDev g, GnnBp4Dev w, A
 
 template <int DV, int DC>
 #ifndef FGNN_GNNBP4_THREADS
-#define FGNN_GNNBP4_THREADS 768  // threads per workgroup (= codeword) of the MFMA kernel; two workgroups share a CU: 6 waves per SIMD
+// threads per workgroup (= codeword) of the MFMA kernel and waves per SIMD the registers are allocated for.  1 024 x 4: one workgroup
+// per CU, 115 VGPRs, no spills, and the 80 tiles of a [[1270,28]] phase divide evenly over 16 waves (195 ms per 16 384 x 10; 768 threads
+// x 2 workgroups = 6 waves per SIMD spill 49 VGPRs and leave 4 of 84 tile slots empty: 201 ms; 512 x 2: 210 ms)
+#define FGNN_GNNBP4_THREADS 1024
 #endif
-__global__ void __launch_bounds__(FGNN_GNNBP4_THREADS, 2 * FGNN_GNNBP4_THREADS / 256)
-gnn_bp4_mfma_kernel(GraphDev g, GnnBp4Dev w, Args a, int tab_floats)
+#ifndef FGNN_GNNBP4_MINW
+#define FGNN_GNNBP4_MINW 4
+#endif
+__global__ void __launch_bounds__(FGNN_GNNBP4_THREADS, FGNN_GNNBP4_MINW)
+gnn_bp4_mfma_kernel(GraphDev g, GnnBp4Dev w, Args a, int tab_floats, int resident)
 {
     FG_LOG_TAB_SETUP();
-    // LDS: [tab_floats] the current phase's per-lane operand tables (staged from L2 at every phase start: operand
-    // reads then cost an LDS access instead of an L2 round trip, which is what the waves were waiting on), then
-    // lx | lz | hlog.  512 threads = 8 waves share the staged tables; two workgroups fit a CU.
+    // LDS: [tab_floats] the per-lane operand tables (an operand read then costs an LDS access instead of an L2 round trip, which
+    // is what the waves were waiting on), then lx | lz | hlog | ssg.  resident: the tables of BOTH phases are staged once at kernel
+    // start (106 KB + 20 KB for [[1270,28]]: one workgroup per CU); otherwise the running phase's tables are staged at every phase
+    // start into one shared region.
     extern __shared__ float lds[];
     constexpr int T = FGNN_GNNBP4_THREADS, NW = T / 64;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -314,15 +321,20 @@ gnn_bp4_mfma_kernel(GraphDev g, GnnBp4Dev w, Args a, int tab_floats)
     }
     float* llr = a.llr_out + (size_t)b * 3 * n;
     const int l = tid & 63, wave = tid >> 6, j = l & 15, q = l >> 4;
-    const float* tab = tabs + l;
+    const float* tab_cn = tabs + l;                                                    // check-phase tables
+    const float* tab = tab_cn + (resident ? (w.tab_vn_msg[0] - w.tab_cn_msg[0]) * 64 : 0);  // qubit-phase tables
     const int vtiles = (n + 15) >> 4, xtiles = (mx + 15) >> 4, ztiles = (mz + 15) >> 4;
     // phase tables are contiguous in the global table: CN phase = [tab_cn_msg[0], tab_vn_msg[0]), VN phase = the rest
     const int cn_first = w.tab_cn_msg[0], vn_first = w.tab_vn_msg[0], vn_end = w.tab_inv + 8;
+    if (resident)
+        for (int i = tid; i < (vn_end - cn_first) * 64; i += T) tabs[i] = w.lane_tab[(size_t)cn_first * 64 + i];
     for (int it = -1; it < a.num_iter; ++it) {
         if (it >= 0) {
             __syncthreads();
-            for (int i = tid; i < (vn_end - vn_first) * 64; i += T) tabs[i] = w.lane_tab[(size_t)vn_first * 64 + i];
-            __syncthreads();
+            if (!resident) {
+                for (int i = tid; i < (vn_end - vn_first) * 64; i += T) tabs[i] = w.lane_tab[(size_t)vn_first * 64 + i];
+                __syncthreads();
+            }
             // ---- UpdateVNEmbeddings on tiles of 16 qubits ----
             for (int tile = wave; tile < vtiles; tile += NW) {
                 const int vraw = tile * 16 + j;
@@ -407,8 +419,10 @@ gnn_bp4_mfma_kernel(GraphDev g, GnnBp4Dev w, Args a, int tab_floats)
             if (it == a.num_iter - 1) break;
         }
         __syncthreads();
-        for (int i = tid; i < (vn_first - cn_first) * 64; i += T) tabs[i] = w.lane_tab[(size_t)cn_first * 64 + i];
-        __syncthreads();
+        if (!resident) {
+            for (int i = tid; i < (vn_first - cn_first) * 64; i += T) tabs[i] = w.lane_tab[(size_t)cn_first * 64 + i];
+            __syncthreads();
+        }
         // ---- UpdateCNEmbeddings: tiles never mix hx and hz checks (the two sides use different weights) ----
         for (int tile = wave; tile < xtiles + ztiles; tile += NW) {
             const int s2 = tile >= xtiles;
@@ -431,7 +445,7 @@ gnn_bp4_mfma_kernel(GraphDev g, GnnBp4Dev w, Args a, int tab_floats)
                 for (int s = 0; s < 5; ++s) { Bin[s] = fcur[s]; Bin[5 + s] = own[s]; }
 #pragma unroll
                 for (int s = 0; s < 5; ++s) fcur[s] = fnxt[s];
-                mlp_tile<10>(tab, w.tab_cn_msg[s2] - cn_first, Bin, msg);
+                mlp_tile<10>(tab_cn, w.tab_cn_msg[s2] - cn_first, Bin, msg);
 #pragma unroll
                 for (int i = 0; i < 5; ++i) acc[i] = (k == 0) ? msg[i] : acc[i] + msg[i];
             }
@@ -440,7 +454,7 @@ gnn_bp4_mfma_kernel(GraphDev g, GnnBp4Dev w, Args a, int tab_floats)
             const float lg = (it >= 0) ? hlog[c] * ssg[c] : 0.0f;
             Bemb[10] = (q == 0) ? lg : 0.0f;
             float nh[5];
-            mlp_tile<11>(tab, w.tab_cn_embed[s2] - cn_first, Bemb, nh);
+            mlp_tile<11>(tab_cn, w.tab_cn_embed[s2] - cn_first, Bemb, nh);
             if (valid) store_row5(hc + (size_t)c * D, q, nh);
         }
     }
@@ -622,12 +636,14 @@ extern "C" int fgnn_gnnbp4_decode(const fgnn_graph* g, const fgnn_gnnbp4_weights
     const size_t lds_bytes = (size_t)(2 * g->d.n + g->d.m) * sizeof(float);
     if (g->d.dvx == 3 && g->d.dvz == 3 && g->d.dc == 6 && !g->force_generic) {
         const int cn_entries = w->d.tab_vn_msg[0] - w->d.tab_cn_msg[0], vn_entries = w->d.tab_inv + 8 - w->d.tab_vn_msg[0];
-        const int tab_floats = (cn_entries > vn_entries ? cn_entries : vn_entries) * 64;
-        const size_t lds2 = lds_bytes + (size_t)(tab_floats + g->d.m) * sizeof(float);  // + the syndrome signs
+        const size_t fixed = lds_bytes + (size_t)g->d.m * sizeof(float);  // + the syndrome signs
+        const int resident = fixed + (size_t)(cn_entries + vn_entries) * 256 <= FGNN_LDS_BUDGET && !getenv("FGNN_GNNBP4_NO_RESIDENT");
+        const int tab_floats = (resident ? cn_entries + vn_entries : (cn_entries > vn_entries ? cn_entries : vn_entries)) * 64;
+        const size_t lds2 = fixed + (size_t)tab_floats * sizeof(float);
         auto kern = gnn_bp4_mfma_kernel<3, 6>;
         if (lds2 > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "code too large for the GNN_BP4 MFMA kernel");
         FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL(kern, dim3(B), dim3(FGNN_GNNBP4_THREADS), lds2, static_cast<hipStream_t>(stream), g->d, w->d, a, tab_floats);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(FGNN_GNNBP4_THREADS), lds2, static_cast<hipStream_t>(stream), g->d, w->d, a, tab_floats, resident);
         FGNN_HIP_CHECK(hipGetLastError());
         return FGNN_OK;
     }
