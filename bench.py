@@ -314,14 +314,20 @@ def main():
             both = conv_e & conv_h
             dl = (exact["llr"] - hw["llr"]).abs().flatten(1).max(1).values
             nb = max(int(both.sum()), 1)
+            # decisions that differ by a stabilizer (difference in the row space of hx / hz <=> zero syndrome under hx_perp / hz_perp)
+            hxp = torch.from_numpy(np.asarray(code.hx_perp)).to("cuda").float()
+            hzp = torch.from_numpy(np.asarray(code.hz_perp)).to("cuda").float()
+            dxb, dzb = (exact["x_hat"] ^ hw["x_hat"])[both].float(), (exact["z_hat"] ^ hw["z_hat"])[both].float()
+            same_class = ~(((dxb @ hxp.t()) % 2).bool().any(1) | ((dzb @ hzp.t()) % 2).bool().any(1))
             hw_info = {"cw_per_s": B / t_hw, "speedup_vs_exact_kernel": t_bp / t_hw,
                        "samples": B, "converged_exact": int(conv_e.sum()), "converged_hw": int(conv_h.sum()),
                        "identical_decisions_all_samples": float(same_dec.float().mean()),
                        "identical_decisions_on_samples_both_converge": float(same_dec[both].float().mean()) if int(both.sum()) else None,
+                       "same_correction_class_on_samples_both_converge": float(same_class.double().mean()) if int(both.sum()) else None,
                        "max_abs_llr_diff_le_1e-4_on_samples_both_converge": float((dl[both] <= 1e-4).sum()) / nb,
                        "median_abs_llr_diff_on_samples_both_converge": float(dl[both].median()) if int(both.sum()) else None}
             out["extras"] = {"bp4_only_cw_per_s (configs[1])": B / t_bp,
-                             "bp4_only_HW_TRANSCENDENTALS_opt_in_NOT_bit_exact (v_exp_f32/v_log_f32, fixed dataflow)": hw_info,
+                             "bp4_only_HW_TRANSCENDENTALS_opt_in_NOT_bit_exact (v_exp_f32/v_log_f32, phi clip points pinned, fixed dataflow)": hw_info,
                              "bp4_only_product_default_cw_per_s (exact saturation shortcut + fixed-point exit, identical outputs)": B / t_bp_s,
                              "sandwich_product_default_cw_per_s (exact saturation shortcut + fixed-point exit, identical outputs)": B / t_s,
                              "sandwich_compacted_cw_per_s (feedback rounds only on flagged samples, same outputs)": B / t_c,

@@ -26,6 +26,9 @@
 #ifndef FGNN_BP4_WAVES
 #define FGNN_BP4_WAVES 7  // waves per SIMD the register allocator must leave room for (LDS admits 5-7 workgroups of 4 waves per CU)
 #endif
+#ifndef FGNN_HWT_PIN_CLIP_POINTS
+#define FGNN_HWT_PIN_CLIP_POINTS 1  // opt-in hardware-transcendental phi: pin phi(clip max) = 0, phi(clip min) = 16.635532
+#endif
 #ifndef FGNN_PHI_STAGE
 #define FGNN_PHI_STAGE 1  // phi evaluations staged together in the regular check-node update (phi_n), must divide DC
 #endif
@@ -86,12 +89,21 @@ struct Mx<true> {
         const float y = exp(-FG_MIN(FG_ABS(a - b), 20.0f));
         return log(1.0f + y) + FG_MAX(a, b);
     }
-    static __device__ __forceinline__ float phi(float x)  // decoding_q.py:365-373, as fg_phi
+    // decoding_q.py:365-373, as fg_phi.  The two clip points are pinned to the values the reference's own known answer fixes
+    // (examples/n1270.ipynb cell 12: saturated marginals log 57 +- deg * 16.635532, i.e. phi(clip max) = 0 and phi(clip min) =
+    // 16.635532 exactly, which TensorFlow's kernels and fgnn_math.h deliver): the units' composition log(exp(x) - 1) misses both
+    // (exp(8.5e-8) may round to 1: log 0), and a decoder whose saturated messages are off sits at a different fixed point.
+    static __device__ __forceinline__ float phi(float x)
     {
         const float xc = FG_CLAMP(x, FG_PHI_MIN, FG_PHI_MAX);
         const float y = exp(xc);
         const float sp = (xc > FG_SOFTPLUS_THRESH) ? xc : log(1.0f + y);
-        return sp - log(y - 1.0f);
+        float r = sp - log(y - 1.0f);
+#if FGNN_HWT_PIN_CLIP_POINTS
+        r = (x >= FG_PHI_MAX) ? 0.0f : r;
+        r = (x <= FG_PHI_MIN) ? 16.6355324f : r;
+#endif
+        return r;
     }
 };
 

@@ -157,7 +157,8 @@ class TannerGraph:
 
     def set_hw_transcendentals(self, on=True):
         """OPT-IN, not bit-exact (FGNN_OPT_HW_TRANSCENDENTALS): boxplus-phi decodes run on v_exp_f32 / v_log_f32 in the fixed
-        dataflow.  Off by default; no parity test and no headline number uses it."""
+        dataflow, phi's clip points pinned to the reference's known-answer values (same saturated fixed point as the exact kernel,
+        different bits in the transient).  Off by default; no parity test and no headline number uses it."""
         check(_lib.lib().fgnn_graph_set_option(self.handle, 3, int(bool(on))))
 
     def force_generic(self, on=True):

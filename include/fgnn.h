@@ -78,8 +78,9 @@ int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords
  * FGNN_OPT_HW_TRANSCENDENTALS (default 0; opt-in, NOT bit-exact, never used by a parity test or by bench.py's headline):
  * boxplus-phi decodes evaluate exp / log on the hardware's v_exp_f32 / v_log_f32 units instead of the shared float32 routines
  * of fgnn_math.h, in the fixed dataflow (the two exact options above are proofs about fgnn_math.h and are ignored while this is
- * set).  Same TensorFlow op structure (softplus thresholds, max-shifted log-sum-exp, _phi clip), ~1 ulp per elementary function,
- * but bits that no CPU oracle reproduces: on non-converged samples decisions may differ from the default path's (chaotic
+ * set).  Same TensorFlow op structure (softplus thresholds, max-shifted log-sum-exp, _phi clip; _phi's two clip points pinned to
+ * 0 and 16.635532, the values the reference's saturation known answer fixes), ~1 ulp per elementary function, but bits that no
+ * CPU oracle reproduces: on non-converged samples decisions may differ from the default path's (chaotic
  * transients).  bench.py reports its rate and its measured agreement with the exact kernel under `extras`. */
 enum { FGNN_OPT_SATURATION_SHORTCUT = 1, FGNN_OPT_FIXED_POINT_EXIT = 2, FGNN_OPT_HW_TRANSCENDENTALS = 3 };
 int fgnn_graph_set_option(fgnn_graph* g, int option, int value);

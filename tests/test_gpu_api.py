@@ -221,12 +221,12 @@ def read_w():
 
 
 def test_hw_transcendentals_are_opt_in_and_what_they_cost_in_fidelity():
-    """FGNN_OPT_HW_TRANSCENDENTALS (v_exp_f32 / v_log_f32, not bit-exact) is off by default.  Switched on, converged samples
-    get the same correction class as from the exact kernel and a published error-rate row stays in its band
-    (/root/reference examples/n882.ipynb cell 2: 3 feedback rounds, p = 0.12 -> 396 / 5000) — but the SATURATED MARGINALS
-    differ: the notebook's known answer (log 57 + 3 * 16.635532, examples/n1270.ipynb cell 12) needs phi(16.635532) == 0 exactly,
-    which TensorFlow's kernels and fgnn_math.h deliver and the hardware units' composition log(exp(x) - 1) does not, so the
-    fixed point sits at a different magnitude.  That is why this path is opt-in only (bench.py reports the same measurements)."""
+    """FGNN_OPT_HW_TRANSCENDENTALS (v_exp_f32 / v_log_f32, not bit-exact) is off by default.  Switched on — with phi's two clip points
+    pinned to the values the reference's known answer fixes (examples/n1270.ipynb cell 12: log 57 + deg * 16.635532) — it reproduces
+    the notebook's saturated marginals, converged samples carry bit-identical marginals on all but the few per cent whose chaotic
+    transient ended on another member of the same correction class, every differing decision is a stabilizer away, and a published
+    error-rate row stays in its band (/root/reference examples/n882.ipynb cell 2: 3 feedback rounds, p = 0.12 -> 396 / 5000).
+    The transient bits are no CPU's, which is why the path is opt-in only (bench.py reports the same measurements)."""
     c = code("ghp882")
     m = _model(c, [64, 16, 16, 16])
     g = m.graph
@@ -245,6 +245,7 @@ def test_hw_transcendentals_are_opt_in_and_what_they_cost_in_fidelity():
         g.set_hw_transcendentals(False)
         g.set_saturation_shortcut(True)
     assert not torch.equal(a["llr"], h["llr"]), "the opt-in path must really run different arithmetic"
+    assert bool(torch.isfinite(h["llr"]).all())
     ones = torch.ones(2048, dtype=torch.uint8, device=g.device)
     both = (g.flag_update(a["x_hat"], a["z_hat"], sx, sz, ones.clone()) == 0) & (g.flag_update(h["x_hat"], h["z_hat"], sx, sz, ones.clone()) == 0)
     assert int(both.sum()) > 1500
@@ -253,11 +254,14 @@ def test_hw_transcendentals_are_opt_in_and_what_they_cost_in_fidelity():
     dx, dz = (a["x_hat"] ^ h["x_hat"]).float(), (a["z_hat"] ^ h["z_hat"]).float()
     equiv = ~(((dx @ hxp.t()) % 2).bool().any(1) | ((dz @ hzp.t()) % 2).bool().any(1))
     same = (a["x_hat"] == h["x_hat"]).all(1) & (a["z_hat"] == h["z_hat"]).all(1)
-    assert float(equiv[both].float().mean()) >= 0.995 and float(same[both].float().mean()) >= 0.95
-    # the exact path reproduces the notebook's saturation values, the hardware path does not (and must not claim to)
-    assert [f"{v:.9g}" for v in a["llr"].amax(dim=(0, 2)).cpu().numpy()] == ["53.9496498", "103.856247", "53.9496498"]
-    mx_hw = h["llr"].amax(dim=(0, 2)).cpu().numpy()
-    assert np.isfinite(mx_hw).all() and (np.abs(mx_hw - np.array([53.9496498, 103.856247, 53.9496498])) > 1e-3).any()
+    assert float(equiv[both].float().mean()) >= 0.999 and float(same[both].float().mean()) >= 0.95
+    # same saturated fixed point: marginals of converged samples agree to the north-star tolerance wherever the decisions do
+    dl = (a["llr"] - h["llr"]).abs().flatten(1).max(1).values
+    assert float((dl[both & same] <= 1e-4).float().mean()) >= 0.99
+    assert float(dl[both].median()) <= 1e-4
+    # both paths reproduce the notebook's saturation values
+    for o in (a, h):
+        assert [f"{v:.9g}" for v in o["llr"].amax(dim=(0, 2)).cpu().numpy()] == ["53.9496498", "103.856247", "53.9496498"]
     bler = float(hls_hat.any(1).float().mean())
     assert abs(bler - 396 / 5000) < 4 * np.sqrt(0.0792 * 0.9208 / 5000) * np.sqrt(2), bler
 
