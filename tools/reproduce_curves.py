@@ -5,6 +5,7 @@ For every published row (p, block errors, num blocks) the same model is simulate
 (capped at `cap`), with all exact optimisations on (outputs identical to the fixed dataflow).  z = difference of the two rates
 in units of the combined binomial standard deviation; |z| < 4 on every row is the acceptance band of the GPU tests.
 usage: python tools/reproduce_curves.py [mult=4] [cap=250000000]  ->  gpurun_out/curves.json
+FGNN_CURVES_HW=1: the same rows on the opt-in hardware-transcendental BP4 (fixed dataflow)  ->  gpurun_out/curves_hw.json
 """
 import json, os, sys, time
 import numpy as np, torch
@@ -51,6 +52,8 @@ for label, cname, wkey, nG, f1, rows in CURVES:
     c = get_code(cname)
     if cname not in graphs:
         graphs[cname] = F.TannerGraph(c)
+        if os.environ.get("FGNN_CURVES_HW"):
+            graphs[cname].set_hw_transcendentals(True)
     g = graphs[cname]
     G = F.Feedback_GNN(code=c, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean", activation="tanh",
                        use_bias=True, graph=g)
@@ -84,4 +87,5 @@ summary = dict(rows=int(zs.size), max_abs_z=float(np.abs(zs).max()), mean_z=floa
                total_blocks=int(total), seconds=time.time() - T0)
 print("\nsummary:", summary)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(dict(mult=mult, cap=cap, summary=summary, curves=out), open("gpurun_out/curves.json", "w"), indent=1)
+json.dump(dict(mult=mult, cap=cap, hw_transcendentals=bool(os.environ.get("FGNN_CURVES_HW")), summary=summary, curves=out),
+          open("gpurun_out/curves_hw.json" if os.environ.get("FGNN_CURVES_HW") else "gpurun_out/curves.json", "w"), indent=1)
