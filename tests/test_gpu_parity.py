@@ -5,6 +5,8 @@ order), so the bar here is EXACT equality of every float and every decision — 
 non-converged samples alike — not a tolerance.  (The oracle itself is pinned to the reference by
 tests/test_oracle_kat.py within the north-star tolerance of 1e-4.)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -400,8 +402,15 @@ def test_gnn_bp4_mfma_and_valu_kernels_agree():
         b = gg.gnn_bp4_decode(gw, tx, tz, iters)
     finally:
         gg.force_generic(False)
+    # codes whose two phases' operand tables do not fit LDS together stage them per phase: same bits (FGNN_GNNBP4_NO_RESIDENT forces it)
+    os.environ["FGNN_GNNBP4_NO_RESIDENT"] = "1"
+    try:
+        c = gg.gnn_bp4_decode(gw, tx, tz, iters)
+    finally:
+        del os.environ["FGNN_GNNBP4_NO_RESIDENT"]
     for k in ("llr", "x_logit_all", "z_logit_all", "x_hat", "z_hat"):
         assert np.array_equal(o[k], b[k].cpu().numpy()), f"VALU {k}"
+        assert np.array_equal(o[k], c[k].cpu().numpy()), f"MFMA, tables staged per phase: {k}"
         assert np.array_equal(o[k], a[k].cpu().numpy()), f"MFMA {k}: {np.abs(o[k].astype(np.float64) - a[k].cpu().numpy()).max()}"
 
 
