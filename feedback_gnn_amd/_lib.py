@@ -55,6 +55,7 @@ _SIGNATURES = {
     "fgnn_merge": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fgnn_residual": (C.c_int, [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 4),
     "fgnn_count_flags": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "fgnn_count_flags_batches": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fgnn_pack_decisions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "fgnn_unpack_decisions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fgnn_sandwich_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),

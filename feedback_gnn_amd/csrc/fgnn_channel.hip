@@ -227,6 +227,44 @@ __global__ void __launch_bounds__(256) count_kernel(const uint8_t* __restrict__ 
     }
 }
 
+// Counters of num_batches consecutive Monte-Carlo batches decoded as ONE launch (sim_ber's fused read-back, utils.py): block j sums
+// the flags of batch j into part[j]; one thread then walks the batches in order: ring[j] = the cumulative counters after batch j,
+// i.e. exactly what num_batches sequential fgnn_count_flags calls would have left behind one after the other.
+__global__ void __launch_bounds__(256) count_batches_kernel(const uint8_t* __restrict__ flags, int batch, unsigned* __restrict__ part)
+{
+    __shared__ unsigned sh[2];
+    if (threadIdx.x < 2) sh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint8_t* f0 = flags + (size_t)blockIdx.x * batch;
+    unsigned f = 0, l = 0;
+    for (int i = threadIdx.x; i < batch; i += blockDim.x) {
+        f += f0[i] & 1u;
+        l += (f0[i] >> 1) & 1u;
+    }
+    if (f) atomicAdd(&sh[0], f);
+    if (l) atomicAdd(&sh[1], l);
+    __syncthreads();
+    if (threadIdx.x < 2) part[2 * blockIdx.x + threadIdx.x] = sh[threadIdx.x];
+}
+
+__global__ void count_scan_kernel(const unsigned* __restrict__ part, int num_batches, int batch, unsigned long long* counts,
+                                  unsigned long long* ring)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    unsigned long long c0 = counts[0], c1 = counts[1], c2 = counts[2];
+    for (int j = 0; j < num_batches; ++j) {
+        c0 += part[2 * j];
+        c1 += part[2 * j + 1];
+        c2 += (unsigned long long)batch;
+        ring[3 * j] = c0;
+        ring[3 * j + 1] = c1;
+        ring[3 * j + 2] = c2;
+    }
+    counts[0] = c0;
+    counts[1] = c1;
+    counts[2] = c2;
+}
+
 // Bit-packed decisions for the all-gather of SURVEY §8(e): row b = the 2n bits [x_hat[b,:] | z_hat[b,:]], most significant bit
 // first inside a byte (numpy.packbits order), ceil(2n/8) bytes per codeword.  One thread per output byte; the 8 input bytes of
 // a thread are contiguous except across the x|z seam, a wave reads 512 consecutive input bytes and writes 64 consecutive bytes.
@@ -386,6 +424,20 @@ extern "C" int fgnn_residual(const fgnn_graph* g, const uint8_t* noise_x, const 
                              const uint8_t* z_hat, int B, uint8_t* s_hat, uint8_t* ls_hat, uint8_t* flags, void* stream)
 {
     return fgnn_residual_rows(g, FGNN_ROWS_HX_PERP, FGNN_ROWS_HZ_PERP, noise_x, noise_z, x_hat, z_hat, B, s_hat, ls_hat, flags, stream);
+}
+
+extern "C" int fgnn_count_flags_batches(const uint8_t* flags, int num_batches, int batch, uint64_t* counts, uint64_t* ring,
+                                        uint32_t* scratch, void* stream)
+{
+    if (!flags || !counts || !ring || !scratch || num_batches < 0 || batch <= 0) return fgnn_fail(FGNN_ERR_ARG, "bad count arguments");
+    if (num_batches == 0) return FGNN_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(count_batches_kernel, dim3(num_batches), dim3(256), 0, st, flags, batch, scratch);
+    FGNN_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(64), 0, st, scratch, num_batches, batch,
+                       reinterpret_cast<unsigned long long*>(counts), reinterpret_cast<unsigned long long*>(ring));
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
 }
 
 extern "C" int fgnn_count_flags(const uint8_t* flags, int B, uint64_t* counts, void* stream)

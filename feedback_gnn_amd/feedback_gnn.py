@@ -140,12 +140,13 @@ class Pauli:
         self.seed = int(seed)
         self.wt = bool(wt)
 
-    def __call__(self, batch_size, p, first_sample=0):
+    def __call__(self, batch_size, p, first_sample=0, out=None):
         """``p`` = physical error rate, or with ``wt=True`` the exact number of erroneous qubits per sample
-        (pauli.py:80-97: positions uniform without replacement, X/Y/Z with probability 1/3 each)."""
+        (pauli.py:80-97: positions uniform without replacement, X/Y/Z with probability 1/3 each).  ``out=(noise_x, noise_z)``
+        writes into given [batch_size, n] buffers."""
         if self.wt:
-            return self.graph.pauli_noise_wt(self.seed, int(p), first_sample, int(batch_size))
-        return self.graph.pauli_noise(self.seed, p, first_sample, int(batch_size))
+            return self.graph.pauli_noise_wt(self.seed, int(p), first_sample, int(batch_size), out=out)
+        return self.graph.pauli_noise(self.seed, p, first_sample, int(batch_size), out=out)
 
 
 class Sandwich_BP_GNN_Evaluation_Model:
@@ -197,14 +198,18 @@ class Sandwich_BP_GNN_Evaluation_Model:
         self._next_sample += self.world_size * batch_size
         return first
 
-    def decode(self, batch_size, p, first_sample=None):
-        """Noise -> syndromes -> sandwich.  Returns dict(noise_x, noise_z, x_hat, z_hat)."""
+    def decode(self, batch_size, p, first_sample=None, noise=None):
+        """Noise -> syndromes -> sandwich.  Returns dict(noise_x, noise_z, x_hat, z_hat).  ``noise=(noise_x, noise_z)``: decode
+        given device arrays instead of drawing ``batch_size`` samples."""
         B = int(batch_size)
         g = self.graph
-        first = self._take_samples(B) if first_sample is None else int(first_sample)
-        ex, ez = self.channel(B, p, first)
+        if noise is None:
+            first = self._take_samples(B) if first_sample is None else int(first_sample)
+            ex, ez = self.channel(B, p, first)
+        else:
+            ex, ez = noise
         sx, sz = g.syndrome(ex, ez)
-        if self._ws_batch != B:
+        if self._ws_batch < B:  # the largest workspace seen serves every smaller batch
             self._workspace = g.sandwich_workspace(B)
             self._ws_batch = B
         L = self.num_layers
@@ -249,6 +254,28 @@ class Sandwich_BP_GNN_Evaluation_Model:
         o = self.decode(batch_size, p)
         _, _, flags = self.graph.residual(o["noise_x"], o["noise_z"], o["x_hat"], o["z_hat"], want_arrays=False)
         return self.graph.count_flags(flags, counts)
+
+
+    def mc_steps(self, batch_size, p, num_batches, counts, ring):
+        """``num_batches`` consecutive Monte-Carlo batches of ``batch_size`` decoded as ONE launch over ``num_batches * batch_size``
+        samples — the very samples (global Philox indices) that ``num_batches`` calls of `mc_step` would draw on this rank — with the
+        counters taken batch by batch: ``ring[j]`` (device int64 [num_batches, 3]) = the counters after batch j, ``counts`` = after the
+        last.  A harness that keeps the reference's batch size (n882.py:45: 5 000) then runs at the rate of a full-chip batch while
+        its stopping rule still sees every batch boundary (`sim_ber`).  No host synchronisation."""
+        k, bs = int(num_batches), int(batch_size)
+        g = self.graph
+        if self.world_size == 1:
+            noise = None
+            first = self._take_samples(k * bs)
+        else:  # this rank's batches are bs-sized blocks world_size * bs apart in the global stream
+            ex = torch.empty((k * bs, g.n), dtype=torch.uint8, device=g.device)
+            ez = torch.empty((k * bs, g.n), dtype=torch.uint8, device=g.device)
+            for j in range(k):
+                self.channel(bs, p, self._take_samples(bs), out=(ex[j * bs:(j + 1) * bs], ez[j * bs:(j + 1) * bs]))
+            noise, first = (ex, ez), None
+        o = self.decode(k * bs, p, first_sample=first, noise=noise)
+        _, _, flags = g.residual(o["noise_x"], o["noise_z"], o["x_hat"], o["z_hat"], want_arrays=False)
+        return g.count_flags_batches(flags, bs, counts, ring)
 
 
 class First_Stage_BP_Model:

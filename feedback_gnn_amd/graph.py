@@ -317,17 +317,26 @@ class TannerGraph:
         return grads
 
     # ---- channel / syndromes / flags / residual ---------------------------------------------------------
-    def pauli_noise(self, seed, p, first_sample, B):
-        ex = self._new((B, self.n), torch.uint8)
-        ez = self._new((B, self.n), torch.uint8)
+    def pauli_noise(self, seed, p, first_sample, B, out=None):
+        """``out=(ex, ez)``: write into the given contiguous uint8 [B, n] tensors (row slices of a larger batch)."""
+        if out is None:
+            ex = self._new((B, self.n), torch.uint8)
+            ez = self._new((B, self.n), torch.uint8)
+        else:
+            ex = self._chk_out(out[0], (B, self.n), torch.uint8, "noise_x")
+            ez = self._chk_out(out[1], (B, self.n), torch.uint8, "noise_z")
         with torch.cuda.device(self.device):  # graph-less entry points run on the current device
             check(_lib.lib().fgnn_pauli_noise(int(seed), float(np.float32(p)), int(first_sample), B, self.n, _ptr(ex), _ptr(ez),
                                               _stream(self.device)))
         return ex, ez
 
-    def pauli_noise_wt(self, seed, wt, first_sample, B):
-        ex = self._new((B, self.n), torch.uint8)
-        ez = self._new((B, self.n), torch.uint8)
+    def pauli_noise_wt(self, seed, wt, first_sample, B, out=None):
+        if out is None:
+            ex = self._new((B, self.n), torch.uint8)
+            ez = self._new((B, self.n), torch.uint8)
+        else:
+            ex = self._chk_out(out[0], (B, self.n), torch.uint8, "noise_x")
+            ez = self._chk_out(out[1], (B, self.n), torch.uint8, "noise_z")
         with torch.cuda.device(self.device):
             check(_lib.lib().fgnn_pauli_noise_wt(int(seed), int(wt), int(first_sample), B, self.n, _ptr(ex), _ptr(ez),
                                                  _stream(self.device)))
@@ -385,6 +394,23 @@ class TannerGraph:
             raise ValueError(f"counts must be a contiguous int64[3] on {self.device}")
         with torch.cuda.device(self.device):  # fgnn_count_flags takes no graph: it runs on the current device
             check(_lib.lib().fgnn_count_flags(_ptr(flags), int(flags.shape[0]), _ptr(counts), _stream(self.device)))
+        return counts
+
+    def count_flags_batches(self, flags, batch, counts, ring):
+        """``flags`` holds ``k = len(flags) // batch`` consecutive batches decoded as one launch: ``ring[j]`` (int64 [k, 3] rows of a
+        device ring) = the counters after batch j, ``counts`` = the last row (fgnn_count_flags_batches)."""
+        B, batch = int(flags.shape[0]), int(batch)
+        if batch <= 0 or B % batch:
+            raise ValueError("flags must hold a whole number of batches")
+        k = B // batch
+        flags = self._chk(flags, (B,), torch.uint8, "flags")
+        for t, shape, name in ((counts, (3,), "counts"), (ring, (k, 3), "ring")):
+            if t.device != self.device or t.dtype not in (torch.int64, torch.uint64) or tuple(t.shape) != shape or not t.is_contiguous():
+                raise ValueError(f"{name} must be a contiguous int64{list(shape)} on {self.device}")
+        scratch = self._new((2 * k,), torch.int32)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().fgnn_count_flags_batches(_ptr(flags), k, batch, _ptr(counts), _ptr(ring), _ptr(scratch),
+                                                      _stream(self.device)))
         return counts
 
     # ---- Sandwich body -----------------------------------------------------------------------------------

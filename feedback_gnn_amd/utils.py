@@ -114,7 +114,8 @@ def shard_range(total, rank, world_size):
 
 def sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=False, num_target_bit_errors=None,
             num_target_block_errors=None, early_stop=True, graph_mode=None, verbose=True,
-            forward_keyboard_interrupt=True, qldpc=True, dist=False, dtype=None, device_counters=True, max_deferred=64):
+            forward_keyboard_interrupt=True, qldpc=True, dist=False, dtype=None, device_counters=True, max_deferred=64,
+            fuse_samples=65536):
     """Simulate until the target number of errors is reached; returns (flagged_rate, bler) per point.
 
     Only the ``qldpc=True`` branch of the reference exists here: ``mc_fun(batch_size=, ebno_db=)`` returns
@@ -141,6 +142,7 @@ def sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=False, num
              "reached target block errors"]
     header = ["p", "Flagged", "BLER", "flag errors", "block errors", "num blocks", "runtime [s]", "status"]
     fast = bool(device_counters) and hasattr(mc_fun, "mc_step") and hasattr(mc_fun, "rewind")
+    fuse = int(fuse_samples) // max(int(batch_size), 1) if (fast and hasattr(mc_fun, "mc_steps")) else 0
     max_it = int(max_mc_iter)
 
     def row(i, st):
@@ -183,14 +185,22 @@ def sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=False, num
         k = 1
         while it < max_it:
             k = max(1, min(k, max_it - it, int(max_deferred)))
-            for j in range(k):
+            j = 0
+            while j < k:
                 if counts is None:
                     probe = mc_fun.mc_step(batch_size, ps[i], None)  # allocates the device counters on the model's device
                     counts = probe
                     ring = torch.zeros((int(max_deferred), 3), dtype=torch.int64, device=counts.device)
+                    ring[0].copy_(counts)
+                    j += 1
+                elif fuse > 1 and k - j > 1:
+                    kk = min(fuse, k - j)
+                    mc_fun.mc_steps(batch_size, ps[i], kk, counts, ring[j:j + kk])
+                    j += kk
                 else:
                     mc_fun.mc_step(batch_size, ps[i], counts)
-                ring[j].copy_(counts)
+                    ring[j].copy_(counts)
+                    j += 1
             it += k
             snap = ring[:k].clone()
             if dist:
@@ -257,12 +267,12 @@ class PlotBER:
     def simulate(self, mc_fun, ebno_dbs, batch_size, max_mc_iter, legend="", add_ber=True, add_bler=False,
                  soft_estimates=False, num_target_bit_errors=None, num_target_block_errors=None, early_stop=True,
                  graph_mode=None, add_results=True, forward_keyboard_interrupt=True, show_fig=False, verbose=True,
-                 qldpc=True, dist=False, device_counters=True):
+                 qldpc=True, dist=False, device_counters=True, fuse_samples=65536):
         flagged, bler = sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=soft_estimates,
                                 num_target_bit_errors=num_target_bit_errors,
                                 num_target_block_errors=num_target_block_errors, early_stop=early_stop, verbose=verbose,
                                 forward_keyboard_interrupt=forward_keyboard_interrupt, qldpc=qldpc, dist=dist,
-                                device_counters=device_counters)
+                                device_counters=device_counters, fuse_samples=fuse_samples)
         if add_results:
             ps = np.atleast_1d(np.asarray(ebno_dbs, dtype=np.float64))
             if add_ber:

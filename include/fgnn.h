@@ -174,6 +174,12 @@ int fgnn_pack_decisions(const uint8_t* x_hat, const uint8_t* z_hat, int B, int n
 int fgnn_unpack_decisions(const uint8_t* packed, int B, int n, uint8_t* x_hat, uint8_t* z_hat, void* stream);
 /* counts[0] += #flagged, counts[1] += #block errors, counts[2] += B (device uint64[3]), misc.py:649-669. */
 int fgnn_count_flags(const uint8_t* flags, int B, uint64_t* counts, void* stream);
+/* The same for num_batches consecutive batches of `batch` samples whose flags lie back to back in flags[num_batches * batch] (the
+ * batches were decoded as one launch): ring[3 j .. 3 j + 2] = the cumulative counters after batch j, counts = ring of the last batch —
+ * what num_batches calls of fgnn_count_flags would have produced one after the other, so the stopping rule of sim_ber
+ * (misc.py:700-738) can be applied batch by batch afterwards.  scratch: device uint32[2 * num_batches].  Current device. */
+int fgnn_count_flags_batches(const uint8_t* flags, int num_batches, int batch, uint64_t* counts, uint64_t* ring, uint32_t* scratch,
+                             void* stream);
 
 /* Sandwich_BP_GNN_Evaluation_Model.call, feedback_gnn.py:293-361, from the syndromes on:
  * decoder 0, then for i = 1..num_layers-1: flag update, GNN i-1, decoder i, masked merge.

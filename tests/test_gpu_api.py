@@ -164,6 +164,54 @@ def test_sim_ber_device_counters_equal_the_per_batch_path():
         assert ref["status"][0] == 4 and ref["status"][2] == 1  # a point that reaches the target and one that hits max iter
 
 
+@pytest.mark.parametrize("rank,world,compact,wt", [(0, 1, False, False), (0, 1, True, False), (1, 3, True, False), (2, 3, False, True)])
+def test_mc_steps_is_k_sequential_mc_steps_in_one_launch(rank, world, compact, wt):
+    """`mc_steps` decodes k batches as one launch and takes the counters batch by batch: every ring row, the final counters and the
+    stream position equal those of k `mc_step` calls — on one rank and on a rank of a sharded stream (whose batches are not
+    contiguous in the global Philox stream), compacted or not, i.i.d. and fixed-weight noise."""
+    c = code("ghp882")
+    kw = dict(wt=True, p0=0.05) if wt else {}
+    p = 45 if wt else 0.11
+    a = _model(c, [64, 16], compact=compact, rank=rank, world_size=world, **kw)
+    b = _model(c, [64, 16], compact=compact, rank=rank, world_size=world, **kw)
+    k, bs = 5, 700
+    ca = torch.zeros(3, dtype=torch.int64, device=a.graph.device)
+    snaps = []
+    for _ in range(k):
+        a.mc_step(bs, p, ca)
+        snaps.append(ca.clone())
+    cb = torch.zeros(3, dtype=torch.int64, device=b.graph.device)
+    ring = torch.zeros((k, 3), dtype=torch.int64, device=b.graph.device)
+    b.mc_steps(bs, p, k, cb, ring)
+    assert torch.equal(torch.stack(snaps), ring) and torch.equal(ca, cb)
+    assert a._next_sample == b._next_sample == k * bs * world
+    assert int(ca[0]) > 0 and int(ca[2]) == k * bs
+    # and it continues from prior counters
+    b.mc_steps(bs, p, 2, cb, ring[:2])
+    a.mc_step(bs, p, ca); a.mc_step(bs, p, ca)
+    assert torch.equal(ca, cb) and int(ring[1][2]) == (k + 2) * bs
+
+
+def test_sim_ber_fused_launches_equal_the_per_batch_path():
+    """The reference's scripts keep batch_size = 5 000 (n882.py:45); sim_ber then decodes fuse_samples // batch_size deferred batches per
+    launch.  Counters, status and stream position equal the per-batch path's, and the fused path is the one that ran."""
+    c = code("ghp882")
+    ref_m, fused_m, plain_m = (_model(c, [64, 16], compact=True) for _ in range(3))
+    pts, kw = [0.13, 0.10, 0.08], dict(batch_size=500, max_mc_iter=40, num_target_block_errors=60, verbose=False, early_stop=False)
+    F.sim_ber(ref_m, pts, device_counters=False, **kw)
+    ref = {k: np.array(v).copy() for k, v in F.sim_ber.last.items()}
+    calls = []
+    orig = fused_m.mc_steps
+    fused_m.mc_steps = lambda *a, **k2: (calls.append(a[2]), orig(*a, **k2))[1]
+    F.sim_ber(fused_m, pts, fuse_samples=4000, **kw)
+    fused = {k: np.array(v).copy() for k, v in F.sim_ber.last.items()}
+    F.sim_ber(plain_m, pts, fuse_samples=0, **kw)
+    for k in ("flag_errors", "block_errors", "num_blocks", "status"):
+        assert np.array_equal(ref[k], fused[k]) and np.array_equal(ref[k], F.sim_ber.last[k]), (k, ref[k], fused[k])
+    assert ref_m._next_sample == fused_m._next_sample == plain_m._next_sample
+    assert calls and max(calls) == 8  # 4000 // 500 batches per launch
+
+
 def test_fixed_weight_noise_and_failure_harvesting():
     """Pauli(wt=True) (pauli.py:80-97) and the dataset-harvesting flow of examples/Generate_dataset.ipynb."""
     c = code("ghp882")

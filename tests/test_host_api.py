@@ -138,6 +138,40 @@ class _StreamModel:
         self._next -= batches * batch_size
 
 
+class _FusedStreamModel(_StreamModel):
+    """... plus mc_steps: k batches as one draw, counters taken batch by batch (the product's fused launch)."""
+
+    def __init__(self):
+        super().__init__()
+        self.fused_calls = 0
+
+    def mc_steps(self, batch_size, p, k, counts, ring):
+        self.fused_calls += 1
+        s, l = self._rows(k * batch_size, p)
+        for j in range(k):
+            sl = slice(j * batch_size, (j + 1) * batch_size)
+            counts += torch.tensor([int(s[sl].any(1).sum()), int(l[sl].any(1).sum()), batch_size])
+            ring[j].copy_(counts)
+        return counts
+
+
+def test_sim_ber_fused_batches_equal_per_batch_path():
+    """Deferred batches decoded several at a time (mc_steps) leave the same counters, status and stream position as the per-batch loop."""
+    pts = [0.3, 0.05, 0.01, 0.002]
+    for kw in (dict(num_target_block_errors=100), dict(num_target_bit_errors=40), dict(num_target_block_errors=100000)):
+        a, b = _StreamModel(), _FusedStreamModel()
+        sim_ber(a, pts, batch_size=64, max_mc_iter=300, verbose=False, early_stop=False, device_counters=False, **kw)
+        ref = {k: np.array(v).copy() for k, v in sim_ber.last.items()}
+        sim_ber(b, pts, batch_size=64, max_mc_iter=300, verbose=False, early_stop=False, device_counters=True, max_deferred=16,
+                fuse_samples=64 * 5, **kw)
+        for k in ("flag_errors", "block_errors", "num_blocks", "status"):
+            assert np.array_equal(ref[k], sim_ber.last[k]), (kw, k, ref[k], sim_ber.last[k])
+        assert a._next == b._next and b.fused_calls > 0
+        c = _FusedStreamModel()
+        sim_ber(c, pts, batch_size=64, max_mc_iter=300, verbose=False, early_stop=False, fuse_samples=0, **kw)
+        assert c.fused_calls == 0 and c._next == a._next
+
+
 def test_sim_ber_device_counter_path_equals_per_batch_path():
     """The deferred read-back must end every point after exactly the batch the per-batch loop ends it with, and leave the
     sample stream where that loop leaves it (so later points see the same samples): identical counters and status for every

@@ -3,7 +3,7 @@ bare device loop?  Same model (ghp882, BP4-64 + nG x (GNN, BP4-16), compacted, p
   (a) model.mc_step in a Python loop with one read-back at the end  (what bench.py's extras time)
   (b) PlotBER.simulate with device counters (the default)
   (c) PlotBER.simulate on the per-batch array path (device_counters=False: what round 1 did)
-python tools/harness_rate.py [p] [nG] [batches]"""
+python tools/harness_rate.py [p] [nG] [batches] [batch_size=65536]"""
 import sys, time, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import feedback_gnn_amd as F
@@ -11,7 +11,7 @@ from helpers import code, WEIGHTS_882
 p = float(sys.argv[1]) if len(sys.argv) > 1 else 0.05
 nG = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 40
-B = 65536
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 65536
 c = code("ghp882")
 G = F.Feedback_GNN(code=c, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean", activation="tanh", use_bias=True)
 F.load_weights(G, WEIGHTS_882)
