@@ -330,6 +330,68 @@ __device__ __forceinline__ bool cn_phi_regular(float* msg, const int (&sl)[DC], 
     return false;
 }
 
+// The min-sum and tanh rules on a check of compile-time degree DC: the DC messages are read once, every intermediate that cn_update
+// parks in the slots (|v| with the sign bit, tanh(v/2)) stays in registers, each slot is written once.  Same float operations in the
+// same order as cn_update<FGNN_CN_MINSUM> / <FGNN_CN_BOXPLUS>.
+template <int DC>
+__device__ __forceinline__ void cn_minsum_regular(float* msg, const int (&sl)[DC], unsigned synd, float factor)
+{
+    const float LARGE = 10000.0f;
+    float a[DC];
+    unsigned ng[DC];
+    unsigned neg = synd;
+    float minv = 0.0f;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        const float v = FG_MIN(FG_MAX(slot_ref(msg, sl[j]), -20.0f), 20.0f);
+        ng[j] = v < 0.0f;
+        neg ^= ng[j];
+        a[j] = FG_ABS(v);
+        minv = (j == 0) ? a[j] : FG_MIN(minv, a[j]);
+    }
+    float min2 = 0.0f, nsum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        float d = a[j] - minv;
+        d = (d == 0.0f) ? LARGE : d;
+        min2 = (j == 0) ? d : FG_MIN(min2, d);
+        nsum = nsum + d;
+    }
+    min2 = min2 + minv;
+    nsum = nsum - (2.0f * LARGE - 1.0f);
+    const float sg = (nsum > 0.0f) ? 1.0f : ((nsum < 0.0f) ? -1.0f : 0.0f);
+    const float dm = 0.5f * (1.0f - sg);
+    const float min_e = (1.0f - dm) * minv + dm * min2;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        const float out = ((a[j] - minv) == 0.0f) ? min_e : minv;
+        slot_ref(msg, sl[j]) = with_sign(out, neg ^ ng[j]) * factor;
+    }
+}
+
+template <int DC>
+__device__ __forceinline__ void cn_tanh_regular(float* msg, const int (&sl)[DC], unsigned synd, float factor)
+{
+    float t[DC];
+    float P = 1.0f;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        float tj = fg_tanh(slot_ref(msg, sl[j]) / 2.0f);
+        tj = (tj == 0.0f) ? 1e-12f : tj;
+        P = (j == 0) ? tj : P * tj;
+        t[j] = tj;
+    }
+    P = P * (synd ? -1.0f : 1.0f);
+    const float clipv = 0.99999988f;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        float q = fg_rcp_unit(t[j]) * P;
+        q = (FG_ABS(q) < 1e-7f) ? 0.0f : q;
+        q = FG_MIN(FG_MAX(q, -clipv), clipv);
+        slot_ref(msg, sl[j]) = (2.0f * fg_atanh(q)) * factor;
+    }
+}
+
 // Runtime-degree phi rule with the exact saturation shortcut of cn_phi_regular: returns true when the whole wave took it.
 template <bool HWT = false>
 __device__ __forceinline__ bool cn_phi_generic(float* msg, const int* __restrict__ slot, int deg, unsigned synd, float factor,
@@ -632,10 +694,10 @@ bp4_kernel(GraphDev g, BpArgs a)
                         else if (cn_one) fast = cn_phi_regular<DC, HWT, false>(lds, sl, synd, a.factor, phi0, opt_shortcut);
                         else fast = cn_phi_regular<DC, HWT, false>(msg, sl, synd, a.factor, phi0, opt_shortcut);
                         cn_slow = !fast || cn_slow;
+                    } else if constexpr (CN_TYPE == FGNN_CN_MINSUM) {
+                        cn_minsum_regular<DC>(msg, sl, synd, a.factor);
                     } else {
-#pragma unroll
-                        for (int j = 0; j < DC; ++j) sl[j] >>= 2;
-                        cn_update<CN_TYPE, HWT>(msg, sl, DC, synd, a.factor);
+                        cn_tanh_regular<DC>(msg, sl, synd, a.factor);
                     }
                 } else {
                     const int c0 = g.cptr[c], deg = g.cptr[c + 1] - c0;
