@@ -170,6 +170,31 @@ def test_regular_and_runtime_degree_kernels_agree(cn_type):
     _assert_bp_equal(o, b, "generic")
 
 
+@pytest.mark.parametrize("cn_type,factor", [("minsum", 0.8), ("boxplus", 0.625), ("boxplus-phi", 0.875)])
+def test_regular_cn_rules_equal_runtime_degree_kernel_at_scale(cn_type, factor):
+    """The register-resident check updates of the (3,3,6)-regular kernel (cn_phi_regular, cn_minsum_regular, cn_tanh_regular) against
+    the runtime-degree kernel — itself pinned to the oracle above — on 8192 codewords x 64 iterations either side of the waterfall:
+    same marginals, decisions and soft syndromes, bit for bit."""
+    gg = gpu_graph("ghp882")
+    B = 8192
+    gg.set_saturation_shortcut(False)
+    try:
+        for p in (0.04, 0.11):
+            ex, ez = gg.pauli_noise(SEED + 11, p, 0, B)
+            sx, sz = gg.syndrome(ex, ez)
+            a = gg.bp4_decode(sx, sz, 64, cn_type, factor, llr_const=llr_const(0.05))
+            gg.force_generic(True)
+            try:
+                b = gg.bp4_decode(sx, sz, 64, cn_type, factor, llr_const=llr_const(0.05))
+            finally:
+                gg.force_generic(False)
+            for k in ("llr", "x_logit", "z_logit"):
+                assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), (cn_type, p, k)
+            assert torch.equal(a["x_hat"], b["x_hat"]) and torch.equal(a["z_hat"], b["z_hat"])
+    finally:
+        gg.set_saturation_shortcut(True)
+
+
 def test_launch_geometry_does_not_change_results():
     B = 24
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes("ghp882", 0.09, B, first=99)
