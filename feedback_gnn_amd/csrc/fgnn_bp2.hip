@@ -188,7 +188,45 @@ __device__ __forceinline__ void cn2_phi_regular(float* msg, const unsigned (&off
     }
 }
 
-// DV/DC > 0 (phi rule only): every bit has DV edges at slots v*DV .. v*DV+DV-1 and every check DC edges whose slot byte offsets
+// _cn_update_minsum (decoding.py:744-850) on a check of compile-time degree DC, registers only: same float operations in the same
+// order as cn_update2<FGNN_CN_MINSUM>.
+template <int DC>
+__device__ __forceinline__ void cn2_minsum_regular(float* msg, const unsigned (&off)[DC], unsigned synd, float factor)
+{
+    const float LARGE = 10000.0f;
+    float a[DC];
+    unsigned ng[DC];
+    unsigned neg = synd;
+    float minv = 0.0f;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        const float v = FG_MIN(FG_MAX(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(msg) + off[j]), -20.0f), 20.0f);
+        ng[j] = v < 0.0f;
+        neg ^= ng[j];
+        a[j] = FG_ABS(v);
+        minv = (j == 0) ? a[j] : FG_MIN(minv, a[j]);
+    }
+    float min2 = 0.0f, nsum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        float d = a[j] - minv;
+        d = (d == 0.0f) ? LARGE : d;
+        min2 = (j == 0) ? d : FG_MIN(min2, d);
+        nsum = nsum + d;
+    }
+    min2 = min2 + minv;
+    nsum = nsum - (2.0f * LARGE - 1.0f);
+    const float sg = (nsum > 0.0f) ? 1.0f : ((nsum < 0.0f) ? -1.0f : 0.0f);
+    const float dm = 0.5f * (1.0f - sg);
+    const float min_e = (1.0f - dm) * minv + dm * min2;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        const float out = ((a[j] - minv) == 0.0f) ? min_e : minv;
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(msg) + off[j]) = with_sign(out, neg ^ ng[j]) * factor;
+    }
+}
+
+// DV/DC > 0 (phi and min-sum rules): every bit has DV edges at slots v*DV .. v*DV+DV-1 and every check DC edges whose slot byte offsets
 // come as one packed 16-byte row of g.cslot16 (the hx rows are the first m_x of it); DV = 0: runtime degrees through the CSR tables.
 template <int CN_TYPE, int DV, int DC>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FGNN_BP2_WAVES))) bp2_kernel(GraphDev g, Bp2Args a)
@@ -262,7 +300,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FGNN_
                     unsigned off[DC];
 #pragma unroll
                     for (int j = 0; j < DC; ++j) off[j] = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-                    cn2_phi_regular<DC>(msg, off, sy, a.factor, f1);
+                    if constexpr (CN_TYPE == FGNN_CN_MINSUM) cn2_minsum_regular<DC>(msg, off, sy, a.factor);
+                    else cn2_phi_regular<DC>(msg, off, sy, a.factor, f1);
                 } else {
                     const int c0 = g.cptr[c], deg = g.cptr[c + 1] - c0;
                     cn_update2<CN_TYPE>(msg, g.cslot + c0, deg, sy, a.factor);
@@ -327,8 +366,9 @@ extern "C" int fgnn_bp2_decode(const fgnn_graph* g, int cn_type, int num_iter, f
     hipStream_t st = static_cast<hipStream_t>(stream);
     // the register-resident check update for (3,6)-regular hx graphs (the [[882,24]] family; cslot16 exists for check degrees up to 8;
     // slots of side 0 come first in the combined numbering, so its byte offsets index this kernel's message area directly)
-    const bool regular = cn_type == FGNN_CN_BOXPLUS_PHI && g->d.cslot16 && !g->force_generic;
-    if (regular && g->d.dvx == 3 && g->d.dc == 6) return launch<FGNN_CN_BOXPLUS_PHI, 3, 6>(g, a, L, lds_bytes, st);
+    const bool regular = g->d.cslot16 && !g->force_generic && g->d.dvx == 3 && g->d.dc == 6;
+    if (regular && cn_type == FGNN_CN_BOXPLUS_PHI) return launch<FGNN_CN_BOXPLUS_PHI, 3, 6>(g, a, L, lds_bytes, st);
+    if (regular && cn_type == FGNN_CN_MINSUM) return launch<FGNN_CN_MINSUM, 3, 6>(g, a, L, lds_bytes, st);
     switch (cn_type) {
     case FGNN_CN_BOXPLUS_PHI: return launch<FGNN_CN_BOXPLUS_PHI>(g, a, L, lds_bytes, st);
     case FGNN_CN_MINSUM: return launch<FGNN_CN_MINSUM>(g, a, L, lds_bytes, st);

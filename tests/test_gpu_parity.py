@@ -459,8 +459,8 @@ def test_binary_syndrome_bp_bit_exact(name, cn_type, factor):
     assert np.array_equal(s0, s1.cpu().numpy()) and np.array_equal(h0, h1.cpu().numpy())
 
 
-@pytest.mark.parametrize("factor", [1.0, 0.875])
-def test_binary_syndrome_bp_regular_kernel_equals_generic(factor):
+@pytest.mark.parametrize("cn_type,factor", [("boxplus-phi", 1.0), ("boxplus-phi", 0.875), ("minsum", 0.8)])
+def test_binary_syndrome_bp_regular_kernel_equals_generic(cn_type, factor):
     """The (3,6)-regular register-resident check update of fgnn_bp2.hip vs the runtime-degree kernel (itself pinned to the oracle
     above) on 4096 syndromes x 64 iterations of [[882,24]] hx, noise on both sides of the waterfall: same bits."""
     gg = gpu_graph("ghp882")
@@ -469,10 +469,10 @@ def test_binary_syndrome_bp_regular_kernel_equals_generic(factor):
         e = gg.bsc_noise(SEED + 5, p, 0, B)
         sx, _ = gg.syndrome(torch.zeros_like(e), e)
         L = float(np.log((1 - 0.2) / 0.2))
-        s1, h1 = gg.bp2_decode(sx, 64, "boxplus-phi", factor, llr_const=L)
+        s1, h1 = gg.bp2_decode(sx, 64, cn_type, factor, llr_const=L)
         gg.force_generic(True)
         try:
-            s0, h0 = gg.bp2_decode(sx, 64, "boxplus-phi", factor, llr_const=L)
+            s0, h0 = gg.bp2_decode(sx, 64, cn_type, factor, llr_const=L)
         finally:
             gg.force_generic(False)
         assert torch.equal(s0.view(torch.int32), s1.view(torch.int32)) and torch.equal(h0, h1)
