@@ -9,6 +9,8 @@
 // in LDS for all iterations; the variable-node phase is a sum and a subtraction per edge, the check-node phase is
 // the phi / min-sum / tanh rule (phi in its log(exp(x)+1) - log(exp(x)-1) form, decoding.py:632-633).
 // Bit-identical to oracle/fgnn_oracle.c: og_bp2_decode.
+#include <cstdlib>
+
 #include "fgnn_internal.h"
 #include "fgnn_math.h"
 #include "fgnn_rng.h"
@@ -149,19 +151,23 @@ __device__ __forceinline__ void phi_gnn_n(const float (&x)[N], float (&out)[N])
 // _cn_update_phi (decoding.py:637-693) for a check of compile-time degree DC: its DC messages are read once, live in registers
 // between the two phi passes (cn_update2 parks phi(|v|) in LDS and reads it back) and are written once; signs travel as bit 31
 // of integer words.  Same float operations in the same order as cn_update2<FGNN_CN_BOXPLUS_PHI>.
+// deg < DC (runtime-degree graphs compiled for a maximum degree): edge j takes part iff j < deg — the guards fold away when deg == DC.
 template <int DC>
-__device__ __forceinline__ void cn2_phi_regular(float* msg, const unsigned (&off)[DC], unsigned synd, float factor, bool f1)
+__device__ __forceinline__ void cn2_phi_regular(float* msg, const unsigned (&off)[DC], int deg, unsigned synd, float factor, bool f1)
 {
     float v[DC], aa[DC];
     uint32_t neg = synd << 31;
 #pragma unroll
     for (int j = 0; j < DC; ++j) {
-        v[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(msg) + off[j]);
+        v[j] = (j < deg) ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(msg) + off[j]) : 1.0f;
         // cn_update2 tests v < 0: a message of -0 counts as positive there, and its parked copy carries no sign either
         neg ^= (v[j] < 0.0f) ? 0x80000000u : 0u;
     }
 #pragma unroll
+    for (int j = 0; j < DC; ++j) aa[j] = 0.0f;
+#pragma unroll
     for (int j = 0; j < DC; j += FGNN_BP2_PHI_STAGE) {
+        if (j >= deg) break;
         float xa[FGNN_BP2_PHI_STAGE], oa[FGNN_BP2_PHI_STAGE];
 #pragma unroll
         for (int k = 0; k < FGNN_BP2_PHI_STAGE; ++k) xa[k] = FG_ABS(v[j + k]);
@@ -171,9 +177,11 @@ __device__ __forceinline__ void cn2_phi_regular(float* msg, const unsigned (&off
     }
     float T = 0.0f;
 #pragma unroll
-    for (int j = 0; j < DC; ++j) T = T + aa[j];
+    for (int j = 0; j < DC; ++j)
+        if (j < deg) T = T + aa[j];
 #pragma unroll
     for (int j = 0; j < DC; j += FGNN_BP2_PHI_STAGE) {
+        if (j >= deg) break;  // (wave-divergent only on runtime-degree graphs)
         float xa[FGNN_BP2_PHI_STAGE], oa[FGNN_BP2_PHI_STAGE];
 #pragma unroll
         for (int k = 0; k < FGNN_BP2_PHI_STAGE; ++k) xa[k] = T - FG_ABS(aa[j + k]);
@@ -183,7 +191,7 @@ __device__ __forceinline__ void cn2_phi_regular(float* msg, const unsigned (&off
             // sign of the parked word with_sign(phi(|v|), v < 0) that cn_update2 reads back
             const uint32_t sg = neg ^ ((v[j + k] < 0.0f) ? 0x80000000u : 0u) ^ (fg_f2u(aa[j + k]) & 0x80000000u);
             const float o = fg_u2f(fg_f2u(oa[k]) ^ sg);
-            *reinterpret_cast<float*>(reinterpret_cast<char*>(msg) + off[j + k]) = f1 ? o : o * factor;
+            if (j + k < deg) *reinterpret_cast<float*>(reinterpret_cast<char*>(msg) + off[j + k]) = f1 ? o : o * factor;
         }
     }
 }
@@ -191,7 +199,7 @@ __device__ __forceinline__ void cn2_phi_regular(float* msg, const unsigned (&off
 // _cn_update_minsum (decoding.py:744-850) on a check of compile-time degree DC, registers only: same float operations in the same
 // order as cn_update2<FGNN_CN_MINSUM>.
 template <int DC>
-__device__ __forceinline__ void cn2_minsum_regular(float* msg, const unsigned (&off)[DC], unsigned synd, float factor)
+__device__ __forceinline__ void cn2_minsum_regular(float* msg, const unsigned (&off)[DC], int deg, unsigned synd, float factor)
 {
     const float LARGE = 10000.0f;
     float a[DC];
@@ -200,19 +208,19 @@ __device__ __forceinline__ void cn2_minsum_regular(float* msg, const unsigned (&
     float minv = 0.0f;
 #pragma unroll
     for (int j = 0; j < DC; ++j) {
-        const float v = FG_MIN(FG_MAX(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(msg) + off[j]), -20.0f), 20.0f);
+        const float v = (j < deg) ? FG_MIN(FG_MAX(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(msg) + off[j]), -20.0f), 20.0f) : 1.0f;
         ng[j] = v < 0.0f;
         neg ^= ng[j];
         a[j] = FG_ABS(v);
-        minv = (j == 0) ? a[j] : FG_MIN(minv, a[j]);
+        minv = (j == 0) ? a[j] : ((j < deg) ? FG_MIN(minv, a[j]) : minv);
     }
     float min2 = 0.0f, nsum = 0.0f;
 #pragma unroll
     for (int j = 0; j < DC; ++j) {
         float d = a[j] - minv;
         d = (d == 0.0f) ? LARGE : d;
-        min2 = (j == 0) ? d : FG_MIN(min2, d);
-        nsum = nsum + d;
+        min2 = (j == 0) ? d : ((j < deg) ? FG_MIN(min2, d) : min2);
+        nsum = (j < deg) ? nsum + d : nsum;
     }
     min2 = min2 + minv;
     nsum = nsum - (2.0f * LARGE - 1.0f);
@@ -222,7 +230,7 @@ __device__ __forceinline__ void cn2_minsum_regular(float* msg, const unsigned (&
 #pragma unroll
     for (int j = 0; j < DC; ++j) {
         const float out = ((a[j] - minv) == 0.0f) ? min_e : minv;
-        *reinterpret_cast<float*>(reinterpret_cast<char*>(msg) + off[j]) = with_sign(out, neg ^ ng[j]) * factor;
+        if (j < deg) *reinterpret_cast<float*>(reinterpret_cast<char*>(msg) + off[j]) = with_sign(out, neg ^ ng[j]) * factor;
     }
 }
 
@@ -300,8 +308,16 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FGNN_
                     unsigned off[DC];
 #pragma unroll
                     for (int j = 0; j < DC; ++j) off[j] = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-                    if constexpr (CN_TYPE == FGNN_CN_MINSUM) cn2_minsum_regular<DC>(msg, off, sy, a.factor);
-                    else cn2_phi_regular<DC>(msg, off, sy, a.factor, f1);
+                    if constexpr (CN_TYPE == FGNN_CN_MINSUM) cn2_minsum_regular<DC>(msg, off, DC, sy, a.factor);
+                    else cn2_phi_regular<DC>(msg, off, DC, sy, a.factor, f1);
+                } else if constexpr (DC > 0 && CN_TYPE == FGNN_CN_MINSUM) {
+                    // runtime degrees up to DC: the slot list is read once (all loads in flight together), then the regular update with
+                    // edge j masked out where j >= deg — no intermediate parked in LDS, no second walk through the index list
+                    const int c0 = g.cptr[c], deg = g.cptr[c + 1] - c0;
+                    unsigned off[DC];
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) off[j] = (j < deg) ? 4u * (unsigned)g.cslot[c0 + j] : 0u;
+                    cn2_minsum_regular<DC>(msg, off, deg, sy, a.factor);
                 } else {
                     const int c0 = g.cptr[c], deg = g.cptr[c + 1] - c0;
                     cn_update2<CN_TYPE>(msg, g.cslot + c0, deg, sy, a.factor);
@@ -369,6 +385,13 @@ extern "C" int fgnn_bp2_decode(const fgnn_graph* g, int cn_type, int num_iter, f
     const bool regular = g->d.cslot16 && !g->force_generic && g->d.dvx == 3 && g->d.dc == 6;
     if (regular && cn_type == FGNN_CN_BOXPLUS_PHI) return launch<FGNN_CN_BOXPLUS_PHI, 3, 6>(g, a, L, lds_bytes, st);
     if (regular && cn_type == FGNN_CN_MINSUM) return launch<FGNN_CN_MINSUM, 3, 6>(g, a, L, lds_bytes, st);
+    // runtime-degree graphs whose hx checks have at most 8 / 16 edges, min-sum rule: the predicated register-resident update (its
+    // compare/select work is cheap, what the loop over the slot list pays for is latency: 17.7 -> 13.0 ms on [[882,24]], 202 -> 153 ms on
+    // the 1000-row over-complete GB matrix, per 65 536 x 64).  The phi rule stays on the loop: masked-out edges would still cost a phi
+    // (measured: 26.2 against 20.8 ms).
+    const int md = (g->force_generic && getenv("FGNN_BP2_NO_PRED")) ? 1 << 30 : g->d.max_cdeg_x;
+    if (md <= 8 && cn_type == FGNN_CN_MINSUM) return launch<FGNN_CN_MINSUM, 0, 8>(g, a, L, lds_bytes, st);
+    if (md <= 16 && cn_type == FGNN_CN_MINSUM) return launch<FGNN_CN_MINSUM, 0, 16>(g, a, L, lds_bytes, st);
     switch (cn_type) {
     case FGNN_CN_BOXPLUS_PHI: return launch<FGNN_CN_BOXPLUS_PHI>(g, a, L, lds_bytes, st);
     case FGNN_CN_MINSUM: return launch<FGNN_CN_MINSUM>(g, a, L, lds_bytes, st);

@@ -171,6 +171,11 @@ extern "C" int fgnn_graph_create(int n, int m_x, int m_z, int nnz_x, const int32
     d.max_vdeg = 0;
     for (int v = 0; v < n; ++v)
         d.max_vdeg = std::max(d.max_vdeg, (vptr[0][v + 1] - vptr[0][v]) + (vptr[1][v + 1] - vptr[1][v]));
+    d.max_cdeg = d.max_cdeg_x = 0;
+    for (int c = 0; c < d.m; ++c) {
+        d.max_cdeg = std::max(d.max_cdeg, cptr[c + 1] - cptr[c]);
+        if (c < m_x) d.max_cdeg_x = std::max(d.max_cdeg_x, cptr[c + 1] - cptr[c]);
+    }
     int rc;
     if (d.dvx > 0 && d.dvz > 0 && d.dc > 0 && d.dc <= 8 && (long long)d.E * 4 < 65536) {
         // BYTE offsets of the slots (slot * 4): a check's LDS addresses are then one mask / shift away from the packed row

@@ -30,6 +30,8 @@ struct GraphDev {
     // uniform degrees, 0 if irregular
     int dvx, dvz, dc;
     int max_vdeg;  // largest number of edges (both sides) at one qubit: the fixed-point detector packs one sign bit per edge
+    int max_cdeg, max_cdeg_x;  // largest check degree over all checks / over the hx checks (binary BP): the predicated register-resident
+                               // check updates of the runtime-degree kernels are compiled for degrees up to 8 and 16
 };
 
 struct fgnn_graph {

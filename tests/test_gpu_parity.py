@@ -472,10 +472,16 @@ def test_binary_syndrome_bp_regular_kernel_equals_generic(cn_type, factor):
         s1, h1 = gg.bp2_decode(sx, 64, cn_type, factor, llr_const=L)
         gg.force_generic(True)
         try:
-            s0, h0 = gg.bp2_decode(sx, 64, cn_type, factor, llr_const=L)
+            s0, h0 = gg.bp2_decode(sx, 64, cn_type, factor, llr_const=L)  # runtime degrees, predicated register-resident update
+            os.environ["FGNN_BP2_NO_PRED"] = "1"
+            try:
+                s2, h2 = gg.bp2_decode(sx, 64, cn_type, factor, llr_const=L)  # runtime degrees, the loop over the slot list
+            finally:
+                del os.environ["FGNN_BP2_NO_PRED"]
         finally:
             gg.force_generic(False)
         assert torch.equal(s0.view(torch.int32), s1.view(torch.int32)) and torch.equal(h0, h1)
+        assert torch.equal(s2.view(torch.int32), s1.view(torch.int32)) and torch.equal(h2, h1)
 
 
 def test_bp_bsc_model_contract_and_published_band():
