@@ -151,23 +151,19 @@ __device__ __forceinline__ void phi_gnn_n(const float (&x)[N], float (&out)[N])
 // _cn_update_phi (decoding.py:637-693) for a check of compile-time degree DC: its DC messages are read once, live in registers
 // between the two phi passes (cn_update2 parks phi(|v|) in LDS and reads it back) and are written once; signs travel as bit 31
 // of integer words.  Same float operations in the same order as cn_update2<FGNN_CN_BOXPLUS_PHI>.
-// deg < DC (runtime-degree graphs compiled for a maximum degree): edge j takes part iff j < deg — the guards fold away when deg == DC.
 template <int DC>
-__device__ __forceinline__ void cn2_phi_regular(float* msg, const unsigned (&off)[DC], int deg, unsigned synd, float factor, bool f1)
+__device__ __forceinline__ void cn2_phi_regular(float* msg, const unsigned (&off)[DC], unsigned synd, float factor, bool f1)
 {
     float v[DC], aa[DC];
     uint32_t neg = synd << 31;
 #pragma unroll
     for (int j = 0; j < DC; ++j) {
-        v[j] = (j < deg) ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(msg) + off[j]) : 1.0f;
+        v[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(msg) + off[j]);
         // cn_update2 tests v < 0: a message of -0 counts as positive there, and its parked copy carries no sign either
         neg ^= (v[j] < 0.0f) ? 0x80000000u : 0u;
     }
 #pragma unroll
-    for (int j = 0; j < DC; ++j) aa[j] = 0.0f;
-#pragma unroll
     for (int j = 0; j < DC; j += FGNN_BP2_PHI_STAGE) {
-        if (j >= deg) break;
         float xa[FGNN_BP2_PHI_STAGE], oa[FGNN_BP2_PHI_STAGE];
 #pragma unroll
         for (int k = 0; k < FGNN_BP2_PHI_STAGE; ++k) xa[k] = FG_ABS(v[j + k]);
@@ -177,11 +173,9 @@ __device__ __forceinline__ void cn2_phi_regular(float* msg, const unsigned (&off
     }
     float T = 0.0f;
 #pragma unroll
-    for (int j = 0; j < DC; ++j)
-        if (j < deg) T = T + aa[j];
+    for (int j = 0; j < DC; ++j) T = T + aa[j];
 #pragma unroll
     for (int j = 0; j < DC; j += FGNN_BP2_PHI_STAGE) {
-        if (j >= deg) break;  // (wave-divergent only on runtime-degree graphs)
         float xa[FGNN_BP2_PHI_STAGE], oa[FGNN_BP2_PHI_STAGE];
 #pragma unroll
         for (int k = 0; k < FGNN_BP2_PHI_STAGE; ++k) xa[k] = T - FG_ABS(aa[j + k]);
@@ -191,13 +185,14 @@ __device__ __forceinline__ void cn2_phi_regular(float* msg, const unsigned (&off
             // sign of the parked word with_sign(phi(|v|), v < 0) that cn_update2 reads back
             const uint32_t sg = neg ^ ((v[j + k] < 0.0f) ? 0x80000000u : 0u) ^ (fg_f2u(aa[j + k]) & 0x80000000u);
             const float o = fg_u2f(fg_f2u(oa[k]) ^ sg);
-            if (j + k < deg) *reinterpret_cast<float*>(reinterpret_cast<char*>(msg) + off[j + k]) = f1 ? o : o * factor;
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(msg) + off[j + k]) = f1 ? o : o * factor;
         }
     }
 }
 
 // _cn_update_minsum (decoding.py:744-850) on a check of compile-time degree DC, registers only: same float operations in the same
-// order as cn_update2<FGNN_CN_MINSUM>.
+// order as cn_update2<FGNN_CN_MINSUM>.  deg < DC (runtime-degree graphs compiled for a maximum degree): edge j takes part iff j < deg;
+// the guards fold away when deg == DC.
 template <int DC>
 __device__ __forceinline__ void cn2_minsum_regular(float* msg, const unsigned (&off)[DC], int deg, unsigned synd, float factor)
 {
@@ -309,7 +304,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FGNN_
 #pragma unroll
                     for (int j = 0; j < DC; ++j) off[j] = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
                     if constexpr (CN_TYPE == FGNN_CN_MINSUM) cn2_minsum_regular<DC>(msg, off, DC, sy, a.factor);
-                    else cn2_phi_regular<DC>(msg, off, DC, sy, a.factor, f1);
+                    else cn2_phi_regular<DC>(msg, off, sy, a.factor, f1);
                 } else if constexpr (DC > 0 && CN_TYPE == FGNN_CN_MINSUM) {
                     // runtime degrees up to DC: the slot list is read once (all loads in flight together), then the regular update with
                     // edge j masked out where j >= deg — no intermediate parked in LDS, no second walk through the index list
