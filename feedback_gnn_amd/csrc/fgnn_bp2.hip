@@ -375,11 +375,14 @@ extern "C" int fgnn_bp2_decode(const fgnn_graph* g, int cn_type, int num_iter, f
     const size_t lds_bytes = (size_t)a.lds_per_cw * sizeof(float) * (size_t)L.cpb;
     if (lds_bytes > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident kernel");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // the register-resident check update for (3,6)-regular hx graphs (the [[882,24]] family; cslot16 exists for check degrees up to 8;
+    // the register-resident check update for (3,6)- and (4,8)-regular hx graphs (the GHP and GB families; cslot16 exists for check degrees up to 8;
     // slots of side 0 come first in the combined numbering, so its byte offsets index this kernel's message area directly)
-    const bool regular = g->d.cslot16 && !g->force_generic && g->d.dvx == 3 && g->d.dc == 6;
-    if (regular && cn_type == FGNN_CN_BOXPLUS_PHI) return launch<FGNN_CN_BOXPLUS_PHI, 3, 6>(g, a, L, lds_bytes, st);
-    if (regular && cn_type == FGNN_CN_MINSUM) return launch<FGNN_CN_MINSUM, 3, 6>(g, a, L, lds_bytes, st);
+    const bool regular = g->d.cslot16 && !g->force_generic;
+    const bool r36 = regular && g->d.dvx == 3 && g->d.dc == 6, r48 = regular && g->d.dvx == 4 && g->d.dc == 8;  // GHP / GB families
+    if (r36 && cn_type == FGNN_CN_BOXPLUS_PHI) return launch<FGNN_CN_BOXPLUS_PHI, 3, 6>(g, a, L, lds_bytes, st);
+    if (r36 && cn_type == FGNN_CN_MINSUM) return launch<FGNN_CN_MINSUM, 3, 6>(g, a, L, lds_bytes, st);
+    if (r48 && cn_type == FGNN_CN_BOXPLUS_PHI) return launch<FGNN_CN_BOXPLUS_PHI, 4, 8>(g, a, L, lds_bytes, st);
+    if (r48 && cn_type == FGNN_CN_MINSUM) return launch<FGNN_CN_MINSUM, 4, 8>(g, a, L, lds_bytes, st);
     // runtime-degree graphs whose hx checks have at most 8 / 16 edges, min-sum rule: the predicated register-resident update (its
     // compare/select work is cheap, what the loop over the slot list pays for is latency: 17.7 -> 13.0 ms on [[882,24]], 202 -> 153 ms on
     // the 1000-row over-complete GB matrix, per 65 536 x 64).  The phi rule stays on the loop: masked-out edges would still cost a phi
