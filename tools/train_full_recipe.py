@@ -2,7 +2,9 @@
 examples/Generate_dataset.ipynb (easy set = BP failures on fixed-weight errors; coarse GNN; hard set = failures of
 BP64 -> GNN -> BP64; mixed set with the hard samples repeated 50x) and examples/Feedback_GNN.ipynb cell 8 (one epoch,
 batch 100, Adam 2e-4, clip 10).  Sample counts are scaled by `scale` (1.0 = the notebook's counts).
-usage: python tools/train_full_recipe.py [scale=0.2] [eval_samples=300000] [hard_scale=scale] [easy_scale=scale] [quirk=0]
+usage: python tools/train_full_recipe.py [scale=0.2] [eval_samples=300000] [hard_scale=scale] [easy_scale=scale] [quirk=0] [seeds=1] [epochs=1]
+`seeds` > 1 repeats the final (mixed-set) training from `seeds` different initialisations / shuffles of the SAME mined data and evaluates each:
+the run-to-run spread of the recipe itself.
 `hard_scale` scales the hard-sample mining alone (the authors collected their ~11 k hard samples over repeated runs of that cell),
 `easy_scale` the easy set of weights 4-40 (theirs holds 439 916 samples = 1.76 passes of cell 5).  `quirk=1` reproduces what
 Generate_dataset.ipynb cell 16 actually assembles for [[882,24]]: the z part of the weight-41..60 hard samples is loaded from the
@@ -22,14 +24,16 @@ eval_samples = int(sys.argv[2]) if len(sys.argv) > 2 else 300000
 hard_scale = float(sys.argv[3]) if len(sys.argv) > 3 else scale
 easy_scale = float(sys.argv[4]) if len(sys.argv) > 4 else scale
 quirk = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+n_seeds = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+epochs = int(sys.argv[7]) if len(sys.argv) > 7 else 1
 c = get_code("ghp882")
 mk = lambda it, **kw: QLDPCBPDecoder(code=c, num_iter=it, normalization_factor=1.0, cn_type="boxplus-phi", **kw)  # noqa: E731
 dec64 = mk(64, stage_one=True)
 g = dec64.graph
 dec16 = mk(16, stage_one=True, graph=g)
 dec16_2 = mk(16, stage_two=True, graph=g)
-newG = lambda: Feedback_GNN(code=c, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean",  # noqa: E731
-                            activation="tanh", use_bias=True, graph=g)
+newG = lambda seed=0: Feedback_GNN(code=c, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean",  # noqa: E731
+                                   activation="tanh", use_bias=True, graph=g, seed=seed)
 log = {}
 T0 = time.time()
 
@@ -43,10 +47,11 @@ def collect(model, weights, batch, iters, cap=None):
     return torch.cat(xs), torch.cat(zs), drawn
 
 
-def train(G, dec_first, X, Z, tag):
+def train(G, dec_first, X, Z, tag, seed=0, epochs=1):
     m1, m2 = First_Stage_BP_Model(c, dec_first), Second_Stage_GNN_BP_Model(c, G, dec16_2, num_iter=16)
     torch.cuda.synchronize(); t0 = time.time()
-    h = np.array(train_second_stage(m1, m2, X, Z, batch_size=100, learning_rate=2e-4, clip_value_grad=10.0, log_every=2000))
+    h = np.array(train_second_stage(m1, m2, X, Z, batch_size=100, learning_rate=2e-4, clip_value_grad=10.0, log_every=4000, seed=seed,
+                                    epochs=epochs))
     torch.cuda.synchronize(); dt = time.time() - t0
     k = max(1, len(h) // 10)
     log[tag] = dict(samples=int(X.shape[0]), steps=len(h), seconds=dt, ms_per_step=dt / len(h) * 1e3,
@@ -86,15 +91,21 @@ print(f"[hard] {Xh.shape[0]} two-stage failures from {dh} samples in {time.time(
 rep = 50
 X = torch.cat([Xe1, Xe2] + [Xh] * rep); Z = torch.cat([Ze1, Ze2] + [Zh] * rep)
 G = newG()
-train(G, dec64, X, Z, "mixed")
+train(G, dec64, X, Z, "mixed", epochs=epochs)
 os.makedirs("gpurun_out", exist_ok=True)
 write_weight_list(G.get_weights(), "gpurun_out/trained_full_ghp882.npz")
+extra = []
+for sd in range(1, n_seeds):
+    Gi = newG(sd)
+    train(Gi, dec64, X, Z, f"mixed_seed{sd}", seed=sd, epochs=epochs)
+    write_weight_list(Gi.get_weights(), f"gpurun_out/trained_full_ghp882_seed{sd}.npz")
+    extra.append((f"trained_here_seed{sd}", Gi))
 
 # 5. evaluation as Feedback_GNN.ipynb cell 10
 Gs = newG(); load_weights(Gs, WEIGHTS_882)
 res = {}
 for p in (0.10, 0.08):
-    for tag, fb in (("bp64", None), ("coarse", Gc), ("trained_here", G), ("shipped", Gs)):
+    for tag, fb in [("bp64", None), ("coarse", Gc), ("trained_here", G), ("shipped", Gs)] + extra:
         decs, fbs, L = ([dec64], [], 1) if fb is None else ([dec64] + [dec16] * 3, [fb] * 3, 4)
         ev = Sandwich_BP_GNN_Evaluation_Model(c, decs, fbs, num_layers=L, seed=777)
         counts = torch.zeros(3, dtype=torch.int64, device=g.device)
@@ -107,6 +118,8 @@ log["eval"] = res
 log["scale"] = scale
 log["hard_scale"] = hard_scale
 log["easy_scale"] = easy_scale
+log["seeds"] = n_seeds
+log["epochs"] = epochs
 log["total_seconds"] = time.time() - T0
 json.dump(log, open("gpurun_out/train_full_ghp882.json", "w"), indent=1)
 print(f"total {time.time()-T0:.1f}s")
