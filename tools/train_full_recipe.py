@@ -66,7 +66,7 @@ bp_only = Sandwich_BP_GNN_Evaluation_Model(c, [dec64], [], num_layers=1, wt=True
 Xe1, Ze1, d1 = collect(bp_only, range(4, 41), 50000, max(1, int(round(50 * easy_scale))))
 Xe2, Ze2, d2 = collect(bp_only, range(41, 61), 50000, it_easy)
 n2 = min(int(Xe2.shape[0]), int(300000 * scale))
-sel = torch.randperm(int(Xe2.shape[0]), device=g.device)[:n2]
+sel = torch.from_numpy(np.random.RandomState(0).permutation(int(Xe2.shape[0]))[:n2]).to(g.device)  # seeded: a device randperm draws a new seed per process
 Xe2, Ze2 = Xe2[sel], Ze2[sel]
 log["easy"] = dict(drawn=d1 + d2, wt_4_40=int(Xe1.shape[0]), wt_41_60_used=n2, seconds=time.time() - t0)
 print(f"[easy] {Xe1.shape[0]} (wt 4-40) + {n2} (wt 41-60) failures from {d1+d2} samples in {time.time()-t0:.1f}s", flush=True)
