@@ -2,7 +2,7 @@
 examples/Generate_dataset.ipynb (easy set = BP failures on fixed-weight errors; coarse GNN; hard set = failures of
 BP64 -> GNN -> BP64; mixed set with the hard samples repeated 50x) and examples/Feedback_GNN.ipynb cell 8 (one epoch,
 batch 100, Adam 2e-4, clip 10).  Sample counts are scaled by `scale` (1.0 = the notebook's counts).
-usage: python tools/train_full_recipe.py [scale=0.2] [eval_samples=300000] [hard_scale=scale] [easy_scale=scale] [quirk=0] [seeds=1] [epochs=1]
+usage: python tools/train_full_recipe.py [scale=0.2] [eval_samples=300000] [hard_scale=scale] [easy_scale=scale] [quirk=0] [seeds=1] [epochs=1] [first_seed=0] [cosine=0]
 `seeds` > 1 repeats the final (mixed-set) training from `seeds` different initialisations / shuffles of the SAME mined data and evaluates each:
 the run-to-run spread of the recipe itself.
 `hard_scale` scales the hard-sample mining alone (the authors collected their ~11 k hard samples over repeated runs of that cell),
@@ -26,7 +26,16 @@ easy_scale = float(sys.argv[4]) if len(sys.argv) > 4 else scale
 quirk = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 n_seeds = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 epochs = int(sys.argv[7]) if len(sys.argv) > 7 else 1
-c = get_code("ghp882")
+seed0 = int(sys.argv[8]) if len(sys.argv) > 8 else 0  # first seed of the final training (seeds seed0 .. seed0 + seeds - 1)
+cosine = int(sys.argv[9]) if len(sys.argv) > 9 else 0  # 1: cosine decay of the learning rate over the final training (the reference's own hint
+                                                       # for multi-epoch runs, Feedback_GNN.ipynb cells 2 / 8: CosineDecay(2e-4, decay_steps))
+CODE = os.environ.get("FGNN_TRAIN_CODE", "ghp882")  # ghp1270: the [[1270,28]] recipe of Generate_dataset.ipynb cells 4-13 (weights 10-60 / 61-80)
+c = get_code(CODE)
+if CODE == "ghp882":
+    W_EASY1, W_EASY2, W_HARD, N_EASY2, W_SPLIT, WSHIP = range(4, 41), range(41, 61), range(4, 61), 300000, 41, WEIGHTS_882
+else:  # easy: 867 278 samples of weight 10-60 + 856 of weight 61-80; hard: weights 10-80 (cell 9)
+    from helpers import WEIGHTS_1270
+    W_EASY1, W_EASY2, W_HARD, N_EASY2, W_SPLIT, WSHIP = range(10, 61), range(61, 81), range(10, 81), 856, 61, WEIGHTS_1270
 mk = lambda it, **kw: QLDPCBPDecoder(code=c, num_iter=it, normalization_factor=1.0, cn_type="boxplus-phi", **kw)  # noqa: E731
 dec64 = mk(64, stage_one=True)
 g = dec64.graph
@@ -50,7 +59,9 @@ def collect(model, weights, batch, iters, cap=None):
 def train(G, dec_first, X, Z, tag, seed=0, epochs=1):
     m1, m2 = First_Stage_BP_Model(c, dec_first), Second_Stage_GNN_BP_Model(c, G, dec16_2, num_iter=16)
     torch.cuda.synchronize(); t0 = time.time()
-    h = np.array(train_second_stage(m1, m2, X, Z, batch_size=100, learning_rate=2e-4, clip_value_grad=10.0, log_every=4000, seed=seed,
+    steps = epochs * ((int(X.shape[0]) + 99) // 100)
+    lr = (lambda t: 2e-4 * 0.5 * (1.0 + np.cos(np.pi * min(t, steps) / steps))) if (cosine and tag.startswith("mixed")) else 2e-4
+    h = np.array(train_second_stage(m1, m2, X, Z, batch_size=100, learning_rate=lr, clip_value_grad=10.0, log_every=4000, seed=seed,
                                     epochs=epochs))
     torch.cuda.synchronize(); dt = time.time() - t0
     k = max(1, len(h) // 10)
@@ -63,9 +74,9 @@ def train(G, dec_first, X, Z, tag, seed=0, epochs=1):
 it_easy = max(1, int(round(50 * scale)))
 t0 = time.time()
 bp_only = Sandwich_BP_GNN_Evaluation_Model(c, [dec64], [], num_layers=1, wt=True)
-Xe1, Ze1, d1 = collect(bp_only, range(4, 41), 50000, max(1, int(round(50 * easy_scale))))
-Xe2, Ze2, d2 = collect(bp_only, range(41, 61), 50000, it_easy)
-n2 = min(int(Xe2.shape[0]), int(300000 * scale))
+Xe1, Ze1, d1 = collect(bp_only, W_EASY1, 50000, max(1, int(round(50 * easy_scale))))
+Xe2, Ze2, d2 = collect(bp_only, W_EASY2, 50000, it_easy if CODE == 'ghp882' else 1)
+n2 = min(int(Xe2.shape[0]), int(N_EASY2 * scale))
 sel = torch.from_numpy(np.random.RandomState(0).permutation(int(Xe2.shape[0]))[:n2]).to(g.device)  # seeded: a device randperm draws a new seed per process
 Xe2, Ze2 = Xe2[sel], Ze2[sel]
 log["easy"] = dict(drawn=d1 + d2, wt_4_40=int(Xe1.shape[0]), wt_41_60_used=n2, seconds=time.time() - t0)
@@ -79,10 +90,16 @@ train(Gc, dec16, Xe1, Ze1, "coarse")
 it_hard = max(1, int(round(200 * hard_scale)))
 t0 = time.time()
 two_stage = Sandwich_BP_GNN_Evaluation_Model(c, [dec64, dec64], [Gc], num_layers=2, wt=True)
-Xh, Zh, dh = collect(two_stage, range(4, 61), 5000, it_hard)
+Xh, Zh, dh = collect(two_stage, W_HARD, 5000, it_hard)
+if CODE != "ghp882":  # cell 13: all hard samples of weight 10-60, 3000 random ones of weight 61-80
+    wt_h = (Xh | Zh).sum(1)
+    hi_idx = torch.nonzero(wt_h >= W_SPLIT).flatten()
+    keep_hi = hi_idx[torch.from_numpy(np.random.RandomState(1).permutation(int(hi_idx.numel()))[:3000]).to(g.device)]
+    keep = torch.cat([torch.nonzero(wt_h < W_SPLIT).flatten(), keep_hi])
+    Xh, Zh = Xh[keep], Zh[keep]
 if quirk:  # cell 16 of Generate_dataset.ipynb: z of the weight 41..60 hard samples := their x
     wt_h = (Xh | Zh).sum(1)
-    hi = wt_h >= 41
+    hi = wt_h >= W_SPLIT
     Zh = torch.where(hi[:, None], Xh, Zh)
 log["hard"] = dict(drawn=dh, found=int(Xh.shape[0]), seconds=time.time() - t0, quirk=quirk)
 print(f"[hard] {Xh.shape[0]} two-stage failures from {dh} samples in {time.time()-t0:.1f}s", flush=True)
@@ -90,21 +107,21 @@ print(f"[hard] {Xh.shape[0]} two-stage failures from {dh} samples in {time.time(
 # 4. mixed set (cell 16): easy + hard x 50, then one epoch from a fresh GNN with the 64/16 pipeline
 rep = 50
 X = torch.cat([Xe1, Xe2] + [Xh] * rep); Z = torch.cat([Ze1, Ze2] + [Zh] * rep)
-G = newG()
-train(G, dec64, X, Z, "mixed", epochs=epochs)
+G = newG(seed0)
+train(G, dec64, X, Z, "mixed", seed=seed0, epochs=epochs)
 os.makedirs("gpurun_out", exist_ok=True)
-write_weight_list(G.get_weights(), "gpurun_out/trained_full_ghp882.npz")
+write_weight_list(G.get_weights(), f"gpurun_out/trained_full_{CODE}.npz")
 extra = []
-for sd in range(1, n_seeds):
+for sd in range(seed0 + 1, seed0 + n_seeds):
     Gi = newG(sd)
     train(Gi, dec64, X, Z, f"mixed_seed{sd}", seed=sd, epochs=epochs)
-    write_weight_list(Gi.get_weights(), f"gpurun_out/trained_full_ghp882_seed{sd}.npz")
+    write_weight_list(Gi.get_weights(), f"gpurun_out/trained_full_{CODE}_seed{sd}.npz")
     extra.append((f"trained_here_seed{sd}", Gi))
 
 # 5. evaluation as Feedback_GNN.ipynb cell 10
-Gs = newG(); load_weights(Gs, WEIGHTS_882)
+Gs = newG(); load_weights(Gs, WSHIP)
 res = {}
-for p in (0.10, 0.08):
+for p in ((0.10, 0.08) if CODE == "ghp882" else (0.12, 0.10)):
     for tag, fb in [("bp64", None), ("coarse", Gc), ("trained_here", G), ("shipped", Gs)] + extra:
         decs, fbs, L = ([dec64], [], 1) if fb is None else ([dec64] + [dec16] * 3, [fb] * 3, 4)
         ev = Sandwich_BP_GNN_Evaluation_Model(c, decs, fbs, num_layers=L, seed=777)
@@ -120,6 +137,9 @@ log["hard_scale"] = hard_scale
 log["easy_scale"] = easy_scale
 log["seeds"] = n_seeds
 log["epochs"] = epochs
+log["cosine"] = cosine
+log["first_seed"] = seed0
 log["total_seconds"] = time.time() - T0
-json.dump(log, open("gpurun_out/train_full_ghp882.json", "w"), indent=1)
+log["code"] = CODE
+json.dump(log, open(f"gpurun_out/train_full_{CODE}.json", "w"), indent=1)
 print(f"total {time.time()-T0:.1f}s")
