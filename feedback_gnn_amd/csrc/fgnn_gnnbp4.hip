@@ -1075,9 +1075,11 @@ extern "C" int fgnn_gnnbp4_decode(const fgnn_graph* g, const fgnn_gnnbp4_weights
     a.zlog_all = z_logit_all;
     a.work = static_cast<float*>(workspace);
     const size_t lds_bytes = (size_t)(2 * g->d.n + g->d.m) * sizeof(float);
+    fgnn_prof_scope prof(g, static_cast<hipStream_t>(stream));
     if (w->general) {
         hipLaunchKernelGGL(gnn_bp4_general_kernel, dim3(B), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), g->d, w->gen, a);
         FGNN_HIP_CHECK(hipGetLastError());
+        prof.done(FGNN_PROF_TAG_GNNBP4, B);
         return FGNN_OK;
     }
     if (g->d.dvx == 3 && g->d.dvz == 3 && g->d.dc == 6 && !g->force_generic) {
@@ -1091,10 +1093,12 @@ extern "C" int fgnn_gnnbp4_decode(const fgnn_graph* g, const fgnn_gnnbp4_weights
         FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(kern, dim3(B), dim3(FGNN_GNNBP4_THREADS), lds2, static_cast<hipStream_t>(stream), g->d, w->d, a, tab_floats, resident);
         FGNN_HIP_CHECK(hipGetLastError());
+        prof.done(FGNN_PROF_TAG_GNNBP4, B);
         return FGNN_OK;
     }
     hipLaunchKernelGGL(g->gnn_factored ? gnn_bp4_kernel<true> : gnn_bp4_kernel<false>, dim3(B), dim3(256), lds_bytes,
                        static_cast<hipStream_t>(stream), g->d, w->d, a);
     FGNN_HIP_CHECK(hipGetLastError());
+    prof.done(FGNN_PROF_TAG_GNNBP4, B);
     return FGNN_OK;
 }

@@ -132,8 +132,10 @@ struct fgnn_device_guard {
         return fgnn_fail(FGNN_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_dev_guard.err))
 
 // Optional per-launch timing (fgnn_profile_*): HIP events on the launch stream around one kernel launch.  `tag` is what
-// fgnn_profile_read reports as `iters`: the BP4 iteration count, or FGNN_PROF_TAG_GNN for a feedback-GNN launch.
+// fgnn_profile_read reports as `iters`: the BP4 iteration count, FGNN_PROF_TAG_GNN for a feedback-GNN launch, FGNN_PROF_TAG_GNNBP4
+// for a GNN_BP4 launch.
 constexpr int FGNN_PROF_TAG_GNN = -1;
+constexpr int FGNN_PROF_TAG_GNNBP4 = -2;  // a GNN_BP4 launch (fgnn_gnnbp4_decode)
 struct fgnn_prof_scope {
     const fgnn_graph* g;
     hipStream_t st;

@@ -513,6 +513,53 @@ class TannerGraph:
             out["rounds"] = rounds
         return out
 
+    def forms_agreement(self, synd_x, synd_z, iters, weights_list, llr_const, chunk=16384):
+        """The sandwich on the same syndromes under the library's default operation sequence and under the reference's formulas
+        term by term (options 4 and 5 = 0: one Dense per edge, feedback_gnn.py:175-184; one log-sum-exp per edge,
+        decoding_q.py:254-273), compared per sample: how many samples end on different decisions, how far the marginals of the
+        last decoder (and of the first decoder alone) are apart — over all samples and over the samples both forms solve (a sample
+        BP does not converge on is chaotic under ANY change of float32 rounding).  Both runs are this library's
+        kernels, each bit-equal to the oracle's restatement of its form; the settings in force are restored."""
+        B = int(synd_x.shape[0])
+        prev = (self.gnn_factored, self.bp4_shared_lse)
+        res = dict(samples=B, decisions_differ=0, max_abs_dllr=0.0, samples_gt_1e_4=0, max_abs_dllr_solved=0.0,
+                   samples_gt_1e_4_solved=0, flagged_default=0, flagged_literal=0, flagged_in_one_form_only=0,
+                   first_decoder=dict(decisions_differ=0, max_abs_dllr=0.0, samples_gt_1e_4=0))
+        try:
+            for s in range(0, B, chunk):
+                sx, sz = synd_x[s:s + chunk].contiguous(), synd_z[s:s + chunk].contiguous()
+                ones = torch.ones(sx.shape[0], dtype=torch.uint8, device=self.device)
+                outs = []
+                for default in (True, False):
+                    self.set_gnn_factored(prev[0] if default else False)
+                    self.set_bp4_shared_lse(prev[1] if default else False)
+                    o = self.sandwich_decode(sx, sz, iters, weights_list, llr_const, return_llr=True)
+                    o["flag"] = self.flag_update(o["x_hat"], o["z_hat"], sx, sz, ones.clone()) != 0
+                    o["first"] = self.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=llr_const, want_logits=False)
+                    outs.append(o)
+                a, b = outs
+                differ = (a["x_hat"] != b["x_hat"]).any(1) | (a["z_hat"] != b["z_hat"]).any(1)
+                d = (a["llr"] - b["llr"]).abs().flatten(1).max(1).values
+                solved = ~(a["flag"] | b["flag"])
+                res["decisions_differ"] += int(differ.sum())
+                res["max_abs_dllr"] = max(res["max_abs_dllr"], float(d.max()))
+                res["samples_gt_1e_4"] += int((d > 1e-4).sum())
+                if bool(solved.any()):
+                    res["max_abs_dllr_solved"] = max(res["max_abs_dllr_solved"], float(d[solved].max()))
+                res["samples_gt_1e_4_solved"] += int((d[solved] > 1e-4).sum())
+                res["flagged_default"] += int(a["flag"].sum())
+                res["flagged_literal"] += int(b["flag"].sum())
+                res["flagged_in_one_form_only"] += int((a["flag"] ^ b["flag"]).sum())
+                fa, fb, f = a["first"], b["first"], res["first_decoder"]
+                d1 = (fa["llr"] - fb["llr"]).abs().flatten(1).max(1).values
+                f["decisions_differ"] += int(((fa["x_hat"] != fb["x_hat"]).any(1) | (fa["z_hat"] != fb["z_hat"]).any(1)).sum())
+                f["max_abs_dllr"] = max(f["max_abs_dllr"], float(d1.max()))
+                f["samples_gt_1e_4"] += int((d1 > 1e-4).sum())
+        finally:
+            self.set_gnn_factored(prev[0])
+            self.set_bp4_shared_lse(prev[1])
+        return res
+
     # ---- OSD-0 (bp_osd.py) -----------------------------------------------------------------------------------------
     def set_basis(self, side, pivot_rows):
         piv = np.ascontiguousarray(pivot_rows, dtype=np.int32)

@@ -94,12 +94,24 @@ int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords
  * FGNN_OPT_BP4_SHARED_LSE (default 1; 0 = one log-sum-exp per edge, term by term): the variable-node update (decoding_q.py:254-273) evaluates, on every hx edge e of a qubit,
  * reduce_logsumexp([-(Z - mu_e), -(Y - mu_e)]) = max(.,.) + log(1 + exp(-|(Z - mu_e) - (Y - mu_e)|)), and the last term's argument is
  * Z - Y for all of the qubit's edges: with the option on it is formed once per qubit and side from the unshifted totals (the per-edge
- * max term stays as it is) — 4 instead of 8 exp/log pairs per qubit and iteration.  Same real-number function; a v->c message moves
- * by the rounding of two subtractions, which BP's transient then amplifies as it amplifies any float32 rounding:
- * converged samples end on the same saturated fixed point, BP4-64 decodes the same number of samples (24 M compared at p = 0.06 ..
- * 0.10 on both codes: differences within 1.8 sigma, both signs, profiles/r3j_bp4_shared_lse_ab.txt) and the 77 published rows land on
- * the same z-scores (max |z| 1.89, profiles/r3k_published_curves_bp4_shared_lse.json).  The oracle restates both forms (og_graph_set_vn_shared_lse); the kernels
- * equal it bit for bit in either.
+ * max term stays as it is) — 4 instead of 8 exp/log pairs per qubit and iteration.  Same real-number function, NOT the same float32
+ * operation sequence: a v->c message moves by the rounding of two subtractions, and BP's transient amplifies that like any other float32
+ * rounding.  What a caller who diffs results against the literal form (option = 0) sees, measured per sample through the
+ * whole sandwich on 65 536 samples per point, options 4 and 5 both on vs both off (profiles/r4_forms_agreement.json,
+ * tests/test_gpu_literal_forms.py; bench.py prints the same comparison for its timed batch as `forms_agreement`):
+ *     [[882,24]] (64, G, 16)   p <= 0.02: 0 samples with a different final decision, marginals within 7.6e-6 on every sample the
+ *                              decoder solves (the 1-4 samples it leaves flagged, under both forms, differ by up to 0.3);
+ *                              p = 0.03: 2 samples (0.003 %);  0.04: 18 (0.03 %);  0.05: 74 (0.11 %);  0.06: 344 (0.5 %);
+ *                              0.08: 2 746 (4.2 %);  0.10: 9 611 (14.7 %) end on a different — equally valid or equally failed — estimate;
+ *     [[1270,28]] (64, G, 64)  p <= 0.02: 0;  0.03: 4;  0.04: 30;  0.05: 126 (0.2 %);  0.06: 426 (0.65 %);  0.08: 4 539 (6.9 %);
+ *                              0.10: 15 177 (23 %).
+ * So up to p = 0.02 — the benchmark's operating point p = 0.01 included — the default is the literal decoder sample by sample within the
+ * north-star tolerance (decisions identical, LLRs within 1e-4); in the waterfall it is the same decoder only STATISTICALLY: BP4-64
+ * decodes the same number of samples (24 M compared at p = 0.06 .. 0.10 on both codes: differences within 1.8 sigma, both signs,
+ * profiles/r3j_bp4_shared_lse_ab.txt), paired block-error counts on 40 M samples agree (profiles/r3v_bp4_lse_forms_mcnemar.json) and the
+ * 77 published rows land on the same z-scores (max |z| 1.89, profiles/r3k_published_curves_bp4_shared_lse.json).  A caller who needs the
+ * reference's operation sequence term by term sets options 4 and 5 to 0 (bench.py: `literal_forms`, 0.83 of the default's rate).  The
+ * oracle restates both forms (og_graph_set_vn_shared_lse); the kernels equal it bit for bit in either.
  * FGNN_OPT_GNN_STREAM (default 1): which kernel runs the factored feedback GNN on a graph with 3, 4 or 5 checks per qubit and side — the
  * streaming VALU kernel (one lane per qubit, weights as scalar operands) or the MFMA-tile kernel ((3,3) only; other degrees: the
  * runtime-degree kernel).  0: never the streaming kernel; 1: wherever it is the faster one (from 4 096 codewords per launch on; smaller
@@ -120,7 +132,7 @@ int fgnn_graph_edges(const fgnn_graph* g, int side, int32_t* chk, int32_t* var);
  * misc.py:639,696): HIP events are recorded on the launch stream right before and after every BP4 / feedback-GNN launch,
  * standalone or inside fgnn_sandwich_decode, up to max_launches (0 disables).  fgnn_profile_read waits for the
  * last one and returns ms / tag / B per launch in host arrays of length cap; tag = num_iter of a BP4 launch,
- * -1 for a feedback-GNN launch. */
+ * -1 for a feedback-GNN launch, -2 for a GNN_BP4 launch (fgnn_gnnbp4_decode). */
 int fgnn_profile_enable(fgnn_graph* g, int max_launches);
 int fgnn_profile_read(fgnn_graph* g, float* ms, int32_t* iters, int32_t* batch, int cap, int32_t* count);
 

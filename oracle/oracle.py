@@ -122,7 +122,15 @@ class OracleGraph:
     (decoding_q.py:35-37); otherwise code.hx_perp / code.hz_perp.
     """
 
-    def __init__(self, code, stage_one=True):
+    FORMS = ("library-default", "literal")
+
+    def __init__(self, code, stage_one=True, *, forms):
+        """``forms`` (required, so that every caller says which restatement it checks against): "literal" = the reference's formulas
+        term by term (one log-sum-exp per edge, decoding_q.py:254-273; one Dense per edge, feedback_gnn.py:175-184, gnn.py:573-610);
+        "library-default" = the two re-associations libfgnn_hip runs by default (FGNN_OPT_BP4_SHARED_LSE, FGNN_OPT_GNN_FACTORED).
+        Both are restated in fgnn_oracle.c; set_gnn_order / set_vn_shared_lse switch them one by one afterwards."""
+        if forms not in self.FORMS:
+            raise ValueError(f"forms must be one of {self.FORMS}")
         L = lib()
         self.code = code
         self.n = int(code.hx.shape[1])
@@ -131,8 +139,9 @@ class OracleGraph:
         rz, cz = _coo(code.hz)
         self.E_x, self.E_z = len(rx), len(rz)
         self.h = L.og_graph_create(self.n, self.m_x, self.m_z, self.E_x, _p(rx), _p(cx), self.E_z, _p(rz), _p(cz))
-        self.gnn_factored = True  # the oracle's default association = the library's (og_graph_set_gnn_order)
-        self.vn_shared_lse = True  # the oracle's default form = the library's (og_graph_set_vn_shared_lse)
+        self.forms = forms
+        self.set_gnn_order(forms == "library-default")
+        self.set_vn_shared_lse(forms == "library-default")
         xp, zp = (code.hz, code.hx) if stage_one else (code.hx_perp, code.hz_perp)
         self.rows_xp, self.rows_zp = int(xp.shape[0]), int(zp.shape[0])
         self.rows_lx, self.rows_lz = int(np.asarray(code.lx).shape[0]), int(np.asarray(code.lz).shape[0])

@@ -68,7 +68,7 @@ def main():
            "crc_iters": np.array(CRC_ITERS), "crc_factors": np.array(CRC_FACTORS, np.float32)}
     for name, p, B, first in BP4_CASES:
         key = f"{name}_p{p:.2f}"
-        og, code = H.oracle_graph(name), H.code(name)
+        og, code = H.oracle_library_forms(name), H.code(name)
         ex, ez = og.pauli_noise(SEED, p, first, B)
         sx, sz = og.syndrome(ex, ez)
         assert np.array_equal(sx, (ez.astype(np.int64) @ np.asarray(code.hx, dtype=np.int64).T) % 2)  # feedback_gnn.py:308
@@ -94,7 +94,7 @@ def main():
 
     # ---------------- gnn.npz: BP-64 failures at p = 0.10, both [[882,24]] weight files ----------------
     name, p, first, B = "ghp882", 0.10, 7000, 384
-    og, code = H.oracle_graph(name), H.code(name)
+    og, code = H.oracle_library_forms(name), H.code(name)
     ex, ez = og.pauli_noise(SEED, p, first, B)
     sx, sz = og.syndrome(ex, ez)
     ng = NR.Graph(code)
@@ -141,7 +141,7 @@ def main():
     print("sandwich numpy: BP-64 failures", int(errors.sum()), "flagged after GNN+16", int(flagged.sum()), "block errors", int(logical.sum()))
     # (ii) frozen bits of the C oracle: two sandwiches on 4 096 samples
     for name, iters, p, B, first in SANDWICHES:
-        og = H.oracle_graph(name)
+        og = H.oracle_library_forms(name)
         ex, ez = og.pauli_noise(SEED, p, first, B)
         sx, sz = og.syndrome(ex, ez)
         o = og.sandwich_decode(sx, sz, iters, [w] * (len(iters) - 1), L0, return_llr=True)
@@ -158,7 +158,7 @@ def main():
     # (the min-sum and tanh check-node rules, binary syndrome BP, OSD-0, GNN_BP4 in both associations and one runtime-shaped setting)
     m = {}
     name, p, first, B = "ghp882", 0.06, 11000, 96
-    og, code = H.oracle_graph(name), H.code(name)
+    og, code = H.oracle_library_forms(name), H.code(name)
     ex, ez = og.pauli_noise(SEED, p, first, B)
     sx, sz = og.syndrome(ex, ez)
     m["first_sample"], m["p"], m["B"] = np.int64(first), np.float32(p), np.int64(B)

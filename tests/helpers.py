@@ -46,9 +46,24 @@ def code(name):
 
 
 @functools.lru_cache(maxsize=None)
-def oracle_graph(name, stage_one=True):
+def _oracle_graph(name, stage_one, forms):
     from oracle.oracle import OracleGraph
-    return OracleGraph(code(name), stage_one=stage_one)
+    return OracleGraph(code(name), stage_one=stage_one, forms=forms)
+
+
+def oracle_library_forms(name, stage_one=True):
+    """The checker of the default parity tests: the oracle's restatement of the operation sequence libfgnn_hip runs BY DEFAULT
+    (FGNN_OPT_GNN_FACTORED = FGNN_OPT_BP4_SHARED_LSE = 1: Dense layers factored, the log-sum-exp term shared per qubit side) — what
+    `gpu_graph(name)` computes out of the box.  Not the reference's formulas term by term: that restatement is `oracle_literal_forms`,
+    and tests/test_gpu_literal_forms.py, test_gpu_bp4_shared_lse.py and test_gpu_gnn_order.py hold the kernels to it with the two
+    options off.  One cached graph per (code, stage_one); tests that flip a form with its setters restore it."""
+    return _oracle_graph(name, stage_one, "library-default")
+
+
+def oracle_literal_forms(name, stage_one=True):
+    """The oracle's restatement of the reference's formulas term by term: one log-sum-exp per edge (decoding_q.py:254-273), one Dense per
+    edge (feedback_gnn.py:175-184, gnn.py:573-610)."""
+    return _oracle_graph(name, stage_one, "literal")
 
 
 @functools.lru_cache(maxsize=None)

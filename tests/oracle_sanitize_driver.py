@@ -28,7 +28,7 @@ O.math_apply("tanh", np.linspace(-12, 12, 1001).astype(np.float32))
 O.math_apply("phi", np.linspace(0, 20, 1001).astype(np.float32))
 O.philox([1, 2, 3, 4], [5, 6])
 for name in ("steane", "rsurf3", "rsurf5", "toric4", "gb48", "gb48_oc", "ghp882"):
-    c, g = H.code(name), H.oracle_graph(name)
+    c, g = H.code(name), H.oracle_library_forms(name)
     B = 3 if name == "ghp882" else 7
     ex, ez = g.pauli_noise(SEED, 0.06, 11, B)
     g.pauli_noise_wt(SEED, min(4, g.n), 0, B)

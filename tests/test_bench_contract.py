@@ -64,6 +64,104 @@ def test_bench_prints_one_contract_line():
     assert t["kind"] == "port" and t["unit"] == "codewords/s" and t["cores"] >= 1 and t["value"] > 0 and "256 codewords" in t["sample"]
     assert t["decisions_identical_to_oracle_on_samples_both_decode"] >= 0.95 and t["samples_both_decode"] >= 250
     assert d["counts"]["samples"] == 2 * 2048
+    # round 4: the parity claim of the headline is checkable in the line.  literal_forms = the same step with the reference's formulas
+    # term by term, timed in the same run; forms_agreement = the first timed batch decoded under both forms, compared per sample
+    lf, fa = d["literal_forms"], d["forms_agreement"]
+    assert lf["unit"] == "codewords/s" and lf["steps"] == 2 and 0 < lf["value"] < 1.05 * d["value"]
+    assert abs(lf["value"] - 2 * 2048 / (lf["ms_per_step"] * 2e-3)) < 1e-6 * lf["value"]
+    assert fa["samples"] == 2048 and fa["p"] == 0.01 and fa["decisions_differ"] == 0 and fa["max_abs_dllr_solved"] <= 1e-4
+    assert set(fa["first_decoder"]) == {"decisions_differ", "max_abs_dllr", "samples_gt_1e_4"}
+    # algorithmic efficiency next to issue utilisation: every exp / log of the fixed dataflow against the hardware transcendental rate
+    assert r["transcendental_evals_per_codeword"] == {"exp": 64 * 16 * 882 + 4 * 882 + 5292 + 882, "log": 64 * 28 * 882 + 4 * 882 + 2 * (5292 + 882)}
+    assert r["transcendental_evals_per_launch"] == 2048 * sum(r["transcendental_evals_per_codeword"].values())
+    hw = r["transcendental_evals_per_launch"] / (r["avg_launch_ms"] * 1e-3) / r["hw_transcendental_peak_per_s"]
+    assert abs(r["frac_of_hw_transcendental_rate"] - hw) < 1e-9 and r["hw_transcendental_peak_per_s"] == 1024 * 64 * 2.4e9 / 8
+
+
+def test_config_shapes_and_the_algorithmic_counts_of_the_other_two_configs():
+    """--config c3 | c4 | c5 = BASELINE.json configs[2] / [3] / [4] at their per-GPU shard; the per-codeword figures the rooflines are
+    priced with: exp / log evaluations of a fixed-dataflow BP4 decode (decoding_q.py:254-273, 365-431, 455-471) and the GNN_BP4 FLOPs of
+    SURVEY.md §8(d) (87.5 MFLOP per [[1270,28]] codeword-iteration, 0.83 GFLOP for 10 iterations with the last check update skipped)."""
+    import bench
+    a = bench.parse_args([])
+    assert (a.config, a.code, a.iters, a.batch) == ("c3", "ghp882", "64,16", 65536)
+    a = bench.parse_args(["--config", "c4"])
+    assert (a.code, a.iters, a.batch) == ("ghp1270", "64,64", 32768) and 8 * a.batch == 262144
+    a = bench.parse_args(["--config", "c5", "--batch", "128"])
+    assert (a.code, a.iters, a.batch) == ("ghp1270", "10", 128) and 8 * bench.CONFIGS["c5"]["batch"] == 131072
+    n, m, E = 882, 882, 5292
+    e1, l1 = bench.bp4_transcendentals_per_codeword(n, m, E, 1, True)
+    e0, l0 = bench.bp4_transcendentals_per_codeword(n, m, E, 0, True)
+    assert (e1 - e0, l1 - l0) == (16 * n, 28 * n)       # shared form: 4 + 4 in the qubit update, 12 + 24 in the check update, per qubit
+    e1, l1 = bench.bp4_transcendentals_per_codeword(n, m, E, 1, False)
+    assert (e1 - e0, l1 - l0) == (20 * n, 32 * n)       # literal form: one log-sum-exp per edge
+    assert (e0, l0) == (4 * n + E + m, 4 * n + 2 * (E + m))  # cal_logit
+    assert abs(bench.HW_TRANSCENDENTAL_PEAK - 1.966e13) < 1e10
+    n, m, E = 1270, 1270, 7620
+    per_it = bench.gnnbp4_flops_per_codeword(n, m, E, 2) - bench.gnnbp4_flops_per_codeword(n, m, E, 1)
+    assert abs(per_it / 1e6 - 87.5) < 0.05
+    f10 = bench.gnnbp4_flops_per_codeword(n, m, E, 10)
+    assert abs(f10 / 1e9 - 0.83) < 0.005 and f10 == 10 * (E * 2 * 2400 + n * 2 * 3200) + 9 * (E * 2 * 2400 + m * 2 * 2440)
+    assert bench.gnnbp4_flops_per_codeword_factored(n, m, E, 10) < f10
+    # 131 072 codewords on 8 GPUs at the f32 peak: the survey's >= 0.087 s
+    assert abs(f10 * 131072 / (8 * bench.GNN_PEAK_TFLOPS * 1e12) - 0.087) < 0.001
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,batch", [("c4", 1024), ("c5", 256)])
+def test_bench_lines_of_the_other_two_configs(config, batch):
+    """`bench.py --config c4` ([[1270,28]] (64, G, 64)) and `--config c5` (GNN_BP4, 10 iterations) print the same contract line: roofline
+    (c5: against the f32 MFMA peak in the reference's FLOPs) and cpu_baseline, GPU == oracle on the sampled codewords; at a batch
+    that has no PMC entry `--require-roofline` turns the null fraction into exit code 5 AFTER the line has been printed."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "2", "--warmup", "1", "--batch", str(batch),
+                          "--cpu-sample", "32", "--no-extras", "--require-roofline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 5 and "--require-roofline" in res.stderr, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert "[[1270,28]]" in d["metric"] and d["unit"] == "codewords/s" and d["n_gpus"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["batch_per_gpu"] == batch and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 2 * batch / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"] and d["counts"]["samples"] == 2 * batch
+    r, c = d["roofline"], d["cpu_baseline"]
+    assert r["frac"] is None and "no entry" in r["traffic_source"] and r["launches_timed"] == 2 and r["avg_launch_ms"] > 0
+    assert c["kind"] == "port" and c["value"] > 0 and c["gpu_matches_oracle_bit_exact"] is True and "32 codewords" in c["sample"]
+    assert d["cpu_baseline_tf_like"]["value"] > 0
+    assert d["forms_agreement"]["samples"] == batch and 0 < d["literal_forms"]["value"] < 1.05 * d["value"]
+    if config == "c5":
+        # untrained (seeded) weights leave marginals within 1e-5 of the argmin boundary: the decisions of such qubits may flip under the
+        # 1e-6 rounding difference of the two associations; none may flip beyond the LLR tolerance
+        assert d["forms_agreement"]["decisions_differ_beyond_llr_tolerance"] == 0
+        assert d["forms_agreement"]["max_decision_margin_where_they_differ"] <= 2e-4
+        assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and d["config"]["gnn_bp4_iters"] == 10
+        assert r["algorithmic_flops_per_launch"] == batch * (10 * (7620 * 2 * 2400 + 1270 * 2 * 3200) + 9 * (7620 * 2 * 2400 + 1270 * 2 * 2440))
+        tf = r["algorithmic_flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12
+        assert abs(r["reference_tflops"] - tf) < 1e-6 * tf and d["forms_agreement"]["max_abs_dllr"] <= 1e-4
+    else:
+        assert d["forms_agreement"]["decisions_differ"] == 0
+        assert r["bound"] == "valu" and d["config"]["bp_iters"] == [64, 64] and "configs[3]" in d["config"]["workload"]
+        assert r["later_decoders_avg_launch_ms"] > 0 and r["gnn"]["launches_timed"] == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,batch", [("c4", 512), ("c5", 128)])
+def test_other_configs_shard_over_two_ranks(config, batch):
+    """`--config c4 | c5 --gpus 2` (two ranks sharing the test box's GPU over gloo): the counters equal ONE process over the same 2 B
+    global samples per step — sharding by global sample index, also for the GNN_BP4 line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["FGNN_BENCH_BACKEND"] = "gloo"
+    common = ["--config", config, "--steps", "2", "--warmup", "1", "--p", "0.08", "--cpu-sample", "0", "--no-extras"]
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", str(batch)] + common,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.lstrip().startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * batch and len(d["per_rank_ms"]) == 2
+    assert d["counts"]["samples"] == 2 * 2 * batch and "literal_forms" in d and "forms_agreement" in d
+    res1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(2 * batch), "--no-build"] + common,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res1.returncode == 0, res1.stderr[-2000:]
+    d1 = json.loads([l for l in res1.stdout.splitlines() if l.lstrip().startswith("{")][0])
+    assert d1["counts"] == d["counts"] and d["counts"]["flagged"] > 0
 
 
 def test_roofline_counts_are_fingerprinted_and_the_fraction_is_a_fraction():
@@ -74,7 +172,11 @@ def test_roofline_counts_are_fingerprinted_and_the_fraction_is_a_fraction():
     import bench
     from feedback_gnn_amd import _lib
     tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    for kind, key in (("bp4", "bp4_ghp882_it64_B65536"), ("gnn", "gnn_ghp882_B65536")):
+    # every BASELINE config's dominant kernel has an entry (round 4): no driver-runnable line prints a null fraction for want of one
+    for key in ("bp4_ghp882_it64_B65536", "gnn_ghp882_B65536", "bp4_ghp1270_it64_B32768", "gnn_ghp1270_B32768", "gnnbp4_ghp1270_it10_B16384"):
+        assert key in tj, key
+    for kind, key in (("bp4", "bp4_ghp882_it64_B65536"), ("gnn", "gnn_ghp882_B65536"), ("bp4", "bp4_ghp1270_it64_B32768"),
+                      ("gnn", "gnn_ghp1270_B32768"), ("gnnbp4", "gnnbp4_ghp1270_it10_B16384")):
         assert len(tj[key]["csrc_sha256"]) == 64 and len(tj[key]["lib_sha256"]) == 64
         ent, why = bench.pmc_entry(kind, key)
         if tj[key]["csrc_sha256"] == _lib.source_fingerprint(kind):

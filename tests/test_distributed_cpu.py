@@ -15,13 +15,13 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from feedback_gnn_amd.utils import allreduce_counts, gather_packed, shard_range
-from helpers import llr_const, oracle_graph
+from helpers import llr_const, oracle_library_forms
 
 TOTAL, P, SEED = 601, 0.09, 0x5EED  # odd: the two shards differ by one row
 
 
 def _counts_for(lo, hi):
-    g = oracle_graph("gb48")
+    g = oracle_library_forms("gb48")
     ex, ez = g.pauli_noise(SEED, P, lo, hi - lo)
     sx, sz = g.syndrome(ex, ez)
     o = g.bp4_decode(sx, sz, 12, "boxplus-phi", 0.8, llr_const=llr_const(0.1))

@@ -15,7 +15,7 @@ import zlib
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, WEIGHTS_882, code, llr_const, oracle_graph
+from helpers import GOLDEN, WEIGHTS_882, code, llr_const, oracle_library_forms
 
 SEED = 0x5EED
 LLR_TOL = 1e-4  # north star: "LLRs within 1e-4"
@@ -41,7 +41,7 @@ class _Oracle:
     kind = "oracle"
 
     def __init__(self, name):
-        self.g = oracle_graph(name)
+        self.g = oracle_library_forms(name)
 
     def noise(self, p, first, B):
         return self.g.pauli_noise(SEED, p, first, B)
@@ -242,7 +242,7 @@ def _check_other_paths(kind):
     G = _load("other_paths.npz")
     name = "ghp882"
     c = code(name)
-    og = oracle_graph(name)
+    og = oracle_library_forms(name)
     first, p, B = int(G["first_sample"]), float(G["p"]), int(G["B"])
     ex, ez = og.pauli_noise(SEED, p, first, B)
     sx, sz = og.syndrome(ex, ez)

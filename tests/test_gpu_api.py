@@ -5,14 +5,14 @@ import pytest
 import torch
 
 import feedback_gnn_amd as F
-from helpers import WEIGHTS_882, code, llr_const, oracle_graph
+from helpers import WEIGHTS_882, code, llr_const, oracle_library_forms
 
 pytestmark = pytest.mark.gpu
 SEED = 0x5EED
 
 
 def _syndromes(name, p, B, first=0):
-    og = oracle_graph(name)
+    og = oracle_library_forms(name)
     ex, ez = og.pauli_noise(SEED, p, first, B)
     sx, sz = og.syndrome(ex, ez)
     return og, ex, ez, sx, sz
@@ -37,7 +37,7 @@ def test_qldpcbpdecoder_stage_one_contract():
     # default (non-stage) mode returns (x_hat, z_hat) only; default cn_type is 'boxplus', factor 0.625, 32 iterations
     dec0 = F.QLDPCBPDecoder(code=c)
     xh, zh = dec0((llr, torch.from_numpy(sx.T.copy()).cuda(), torch.from_numpy(sz.T.copy()).cuda()))
-    o0 = oracle_graph("ghp882", False).bp4_decode(sx, sz, 32, "boxplus", 0.625, llr_const=llr_const(0.05))
+    o0 = oracle_library_forms("ghp882", False).bp4_decode(sx, sz, 32, "boxplus", 0.625, llr_const=llr_const(0.05))
     assert np.array_equal(o0["x_hat"], xh.cpu().numpy()) and np.array_equal(o0["z_hat"], zh.cpu().numpy().astype(np.uint8))
 
 
@@ -288,7 +288,7 @@ def test_sim_ber_fused_launches_equal_the_per_batch_path():
 def test_fixed_weight_noise_and_failure_harvesting():
     """Pauli(wt=True) (pauli.py:80-97) and the dataset-harvesting flow of examples/Generate_dataset.ipynb."""
     c = code("ghp882")
-    og = oracle_graph("ghp882")
+    og = oracle_library_forms("ghp882")
     m = _model(c, [64], wt=True, p0=0.05)
     g = m.graph
     ex, ez = g.pauli_noise_wt(SEED, 37, 100, 500)
@@ -310,7 +310,7 @@ def test_fixed_weight_noise_and_failure_harvesting():
 
 def test_first_and_second_stage_models():
     c = code("ghp882")
-    og = oracle_graph("ghp882")
+    og = oracle_library_forms("ghp882")
     dec1 = F.QLDPCBPDecoder(code=c, num_iter=16, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True)
     dec2 = F.QLDPCBPDecoder(code=c, num_iter=16, normalization_factor=1.0, cn_type="boxplus-phi", stage_two=True, graph=dec1.graph)
     G = F.Feedback_GNN(code=c, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean", activation="tanh",

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import WEIGHTS_882, WEIGHTS_1270, code, gpu_graph, llr_const, oracle_graph, to_gpu
+from helpers import WEIGHTS_882, WEIGHTS_1270, code, gpu_graph, llr_const, oracle_library_forms, to_gpu
 
 pytestmark = pytest.mark.gpu
 SEED = 0x5EED
@@ -21,7 +21,7 @@ KEYS = ("llr", "x_logit", "z_logit", "msg_x", "msg_z", "x_hat", "z_hat")
 
 class _shared:
     def __init__(self, name, on):
-        self.og, self.gg, self.on = oracle_graph(name), gpu_graph(name), on
+        self.og, self.gg, self.on = oracle_library_forms(name), gpu_graph(name), on
 
     def __enter__(self):
         self.prev = self.gg.bp4_shared_lse
@@ -80,7 +80,7 @@ def test_both_forms_bit_exact_in_every_kernel_variant(name, p, iters, cn, factor
 
 def test_the_two_forms_differ_by_rounding_in_one_update_and_meet_on_the_fixed_point():
     name, B = "ghp882", 512
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     ex, ez = og.pauli_noise(SEED, 0.05, 9000, B)
     sx, sz = og.syndrome(ex, ez)
     tx, tz = to_gpu(sx), to_gpu(sz)

@@ -11,7 +11,7 @@ on either reaches the same decisions on the samples it decodes.
 import numpy as np
 import pytest
 
-from helpers import WEIGHTS_882, WEIGHTS_1270, code, gpu_graph, llr_const, oracle_graph, to_gpu
+from helpers import WEIGHTS_882, WEIGHTS_1270, code, gpu_graph, llr_const, oracle_library_forms, to_gpu
 
 pytestmark = pytest.mark.gpu
 
@@ -22,7 +22,7 @@ class _order:
     """Both the GPU graph and the oracle graph in one association, restored on exit (the graphs are shared by the whole session)."""
 
     def __init__(self, name, factored):
-        self.og, self.gg, self.f = oracle_graph(name), gpu_graph(name), factored
+        self.og, self.gg, self.f = oracle_library_forms(name), gpu_graph(name), factored
 
     def __enter__(self):
         self.prev = self.gg.gnn_factored
@@ -38,7 +38,7 @@ class _order:
 
 
 def _bp_inputs(name, p, B, first=0, iters=64):
-    og = oracle_graph(name)
+    og = oracle_library_forms(name)
     ex, ez = og.pauli_noise(SEED, p, first, B)
     sx, sz = og.syndrome(ex, ez)
     o = og.bp4_decode(sx, sz, iters, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
@@ -96,7 +96,7 @@ def test_streaming_kernel_on_the_other_regular_degrees(name, B):
     logits of both signs and of saturated size."""
     from feedback_gnn_amd.graph import GnnWeights
     from feedback_gnn_amd.weights_io import read_weight_list
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     assert gg.info()["regular"] and gg.gnn_factored and gg.gnn_stream
     ex, ez = og.pauli_noise(SEED, 0.06, 3, B)
     sx, sz = og.syndrome(ex, ez)
@@ -183,7 +183,7 @@ def _sandwich_both_orders(name, wfile, iters, p, compact, stream="always"):
     from feedback_gnn_amd.graph import GnnWeights
     from feedback_gnn_amd.weights_io import read_weight_list
     B = 192
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     ex, ez = og.pauli_noise(SEED, p, 999, B)
     sx, sz = og.syndrome(ex, ez)
     w = read_weight_list(wfile)
@@ -227,7 +227,7 @@ def test_gnn_bp4_both_orders_bit_exact(name, B, iters):
     for shp in GNNBP4_SHAPES:
         lim = 0.6 if len(shp) == 1 else np.sqrt(6.0 / (shp[0] + shp[1]))
         w.append(rng.uniform(-lim, lim, size=shp).astype(np.float32))
-    og0 = oracle_graph(name)
+    og0 = oracle_library_forms(name)
     ex, ez = og0.pauli_noise(SEED, 0.05, 40, B)
     sx, sz = og0.syndrome(ex, ez)
     res = {}

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import WEIGHTS_882, WEIGHTS_1270, code, gpu_graph, llr_const, oracle_graph, to_gpu
+from helpers import WEIGHTS_882, WEIGHTS_1270, code, gpu_graph, llr_const, oracle_library_forms, to_gpu
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +19,7 @@ SEED = 0x5EED
 
 
 def _noise_and_syndromes(name, p, B, first=0):
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     ex, ez = og.pauli_noise(SEED, p, first, B)
     gx, gz = gg.pauli_noise(SEED, p, first, B)
     assert np.array_equal(ex, gx.cpu().numpy()) and np.array_equal(ez, gz.cpu().numpy())
@@ -44,7 +44,7 @@ def test_bp4_phi_bit_exact(name, p, iters):
     B = 48
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, p, B)
     L0 = llr_const(0.05)
-    o = oracle_graph(name).bp4_decode(sx, sz, iters, "boxplus-phi", 1.0, llr_const=L0, return_msgs=True)
+    o = oracle_library_forms(name).bp4_decode(sx, sz, iters, "boxplus-phi", 1.0, llr_const=L0, return_msgs=True)
     g = gpu_graph(name).bp4_decode(tx, tz, iters, "boxplus-phi", 1.0, llr_const=L0, return_msgs=True)
     _assert_bp_equal(o, g, f"{name} p={p} it={iters}")
 
@@ -54,7 +54,7 @@ def test_bp4_cn_variants_bit_exact(cn_type, factor):
     B = 40
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes("ghp882", 0.07, B, first=1000)
     L0 = llr_const(0.3)
-    o = oracle_graph("ghp882").bp4_decode(sx, sz, 24, cn_type, factor, llr_const=L0, return_msgs=True)
+    o = oracle_library_forms("ghp882").bp4_decode(sx, sz, 24, cn_type, factor, llr_const=L0, return_msgs=True)
     g = gpu_graph("ghp882").bp4_decode(tx, tz, 24, cn_type, factor, llr_const=L0, return_msgs=True)
     _assert_bp_equal(o, g, cn_type)
 
@@ -65,7 +65,7 @@ def test_bp4_small_and_irregular_codes(name, cn_type):
     B = 77  # not a multiple of codewords-per-block: exercises the padded last workgroup
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, 0.08, B)
     L0 = llr_const(0.05)
-    o = oracle_graph(name).bp4_decode(sx, sz, 12, cn_type, 0.8, llr_const=L0, return_msgs=True)
+    o = oracle_library_forms(name).bp4_decode(sx, sz, 12, cn_type, 0.8, llr_const=L0, return_msgs=True)
     g = gpu_graph(name).bp4_decode(tx, tz, 12, cn_type, 0.8, llr_const=L0, return_msgs=True)
     _assert_bp_equal(o, g, f"{name} {cn_type}")
 
@@ -73,7 +73,7 @@ def test_bp4_small_and_irregular_codes(name, cn_type):
 def test_bp4_message_step_with_edge_cases():
     """One iteration from crafted c->v messages: exact zeros, +-20, duplicates, tiny values, huge values."""
     name, B = "ghp882", 16
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     rng = np.random.RandomState(1)
     mx = rng.uniform(-10, 10, size=(B, og.E_x)).astype(np.float32)
     mz = rng.uniform(-10, 10, size=(B, og.E_z)).astype(np.float32)
@@ -99,7 +99,7 @@ def test_bp4_message_step_with_edge_cases():
 def test_bp4_non_stage_one_logits():
     """Soft syndrome over the dense hx_perp/hz_perp rows (decoding_q.py:33-34 when not stage_one)."""
     name, B = "gb48", 33
-    og, gg = oracle_graph(name, False), gpu_graph(name, False)
+    og, gg = oracle_library_forms(name, False), gpu_graph(name, False)
     ex, ez = og.pauli_noise(SEED, 0.06, 0, B)
     sx, sz = og.syndrome(ex, ez)
     o = og.bp4_decode(sx, sz, 10, "boxplus-phi", 0.625, llr_const=llr_const(0.1))
@@ -113,7 +113,7 @@ def test_feedback_gnn_bit_exact(name, wfile, p):
     from feedback_gnn_amd.graph import GnnWeights
     from feedback_gnn_amd.weights_io import read_weight_list
     B = 24
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, p, B)
     w = read_weight_list(wfile)
     o = og.bp4_decode(sx, sz, 64, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
@@ -132,7 +132,7 @@ def test_sandwich_and_residual_bit_exact(name, wfile, iters, p, compact):
     from feedback_gnn_amd.graph import GnnWeights
     from feedback_gnn_amd.weights_io import read_weight_list
     B = 96
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, p, B, first=12345)
     w = read_weight_list(wfile)
     gw = GnnWeights(w, gg.device)
@@ -159,7 +159,7 @@ def test_regular_and_runtime_degree_kernels_agree(cn_type):
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes("ghp882", 0.09, B, first=31)
     gg = gpu_graph("ghp882")
     assert gg.info()["regular"] == 1
-    o = oracle_graph("ghp882").bp4_decode(sx, sz, 20, cn_type, 0.8, llr_const=llr_const(0.05), return_msgs=True)
+    o = oracle_library_forms("ghp882").bp4_decode(sx, sz, 20, cn_type, 0.8, llr_const=llr_const(0.05), return_msgs=True)
     a = gg.bp4_decode(tx, tz, 20, cn_type, 0.8, llr_const=llr_const(0.05), return_msgs=True)
     gg.force_generic(True)
     try:
@@ -199,7 +199,7 @@ def test_launch_geometry_does_not_change_results():
     B = 24
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes("ghp882", 0.09, B, first=99)
     gg = gpu_graph("ghp882")
-    o = oracle_graph("ghp882").bp4_decode(sx, sz, 16, "boxplus-phi", 1.0, llr_const=llr_const(0.05), return_msgs=True)
+    o = oracle_library_forms("ghp882").bp4_decode(sx, sz, 16, "boxplus-phi", 1.0, llr_const=llr_const(0.05), return_msgs=True)
     try:
         for tpc, cpb in ((256, 1), (128, 2), (512, 1), (1024, 1), (64, 4)):
             gg.set_launch(tpc, cpb)
@@ -214,7 +214,7 @@ def test_gnn_mfma_and_valu_kernels_agree():
     from feedback_gnn_amd.graph import GnnWeights
     from feedback_gnn_amd.weights_io import read_weight_list
     name, B = "ghp882", 19
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, 0.11, B, first=4242)
     w = read_weight_list(WEIGHTS_882)
     # random weights too: the trained ones could hide a permutation error in a near-zero column
@@ -242,7 +242,7 @@ def test_small_launch_geometry_is_exact(name, wfile):
     must give the same bits for the first samples of a small launch and of a large one (and both equal the oracle)."""
     from feedback_gnn_amd.graph import GnnWeights
     from feedback_gnn_amd.weights_io import read_weight_list
-    gg, og = gpu_graph(name), oracle_graph(name)
+    gg, og = gpu_graph(name), oracle_library_forms(name)
     L0 = llr_const(0.05)
     w = read_weight_list(wfile)
     gw = GnnWeights(w, gg.device)
@@ -279,7 +279,7 @@ def test_saturation_shortcut_is_exact(name, p):
     B = 64
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, p, B, first=777)
     gg = gpu_graph(name)
-    o = oracle_graph(name).bp4_decode(sx, sz, 64, "boxplus-phi", 1.0, llr_const=llr_const(0.05), return_msgs=True)
+    o = oracle_library_forms(name).bp4_decode(sx, sz, 64, "boxplus-phi", 1.0, llr_const=llr_const(0.05), return_msgs=True)
     assert np.abs(o["msg_x"]).max() == np.float32(16.635532)  # saturated state reached
     try:
         for on in (True, False):
@@ -288,7 +288,7 @@ def test_saturation_shortcut_is_exact(name, p):
             _assert_bp_equal(o, g, f"shortcut={on}")
         # per-qubit channel LLRs (second-stage style input) and a normalisation factor != 1
         llr = np.random.RandomState(3).uniform(0.3, 3.0, size=(B, 3, gg.n)).astype(np.float32)
-        o2 = oracle_graph(name).bp4_decode(sx, sz, 40, "boxplus-phi", 0.8, llr_ch=llr, return_msgs=True)
+        o2 = oracle_library_forms(name).bp4_decode(sx, sz, 40, "boxplus-phi", 0.8, llr_ch=llr, return_msgs=True)
         for on in (True, False):
             gg.set_saturation_shortcut(on)
             _assert_bp_equal(o2, gg.bp4_decode(tx, tz, 40, "boxplus-phi", 0.8, llr_ch=to_gpu(llr), return_msgs=True),
@@ -310,7 +310,7 @@ def test_fixed_point_exit_is_exact(name, p, iters, factor):
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, p, B, first=4242)
     gg = gpu_graph(name)
     L0 = llr_const(0.05)
-    o = oracle_graph(name).bp4_decode(sx, sz, iters, "boxplus-phi", factor, llr_const=L0, return_msgs=True)
+    o = oracle_library_forms(name).bp4_decode(sx, sz, iters, "boxplus-phi", factor, llr_const=L0, return_msgs=True)
     try:
         for shortcut, fpe in ((True, True), (True, False), (False, True)):
             gg.set_saturation_shortcut(shortcut)
@@ -321,8 +321,8 @@ def test_fixed_point_exit_is_exact(name, p, iters, factor):
         gg.set_fixed_point_exit(True)
         # chained launches (stage-two style): restart from the returned messages, with per-qubit channel LLRs
         llr = np.random.RandomState(5).uniform(0.5, 3.0, size=(B, 3, gg.n)).astype(np.float32)
-        o1 = oracle_graph(name).bp4_decode(sx, sz, iters, "boxplus-phi", factor, llr_ch=llr, return_msgs=True)
-        o2 = oracle_graph(name).bp4_decode(sx, sz, 5, "boxplus-phi", factor, llr_ch=llr, msg_init=(o1["msg_x"], o1["msg_z"]),
+        o1 = oracle_library_forms(name).bp4_decode(sx, sz, iters, "boxplus-phi", factor, llr_ch=llr, return_msgs=True)
+        o2 = oracle_library_forms(name).bp4_decode(sx, sz, 5, "boxplus-phi", factor, llr_ch=llr, msg_init=(o1["msg_x"], o1["msg_z"]),
                                            return_msgs=True)
         g1 = gg.bp4_decode(tx, tz, iters, "boxplus-phi", factor, llr_ch=to_gpu(llr), return_msgs=True)
         g2 = gg.bp4_decode(tx, tz, 5, "boxplus-phi", factor, llr_ch=to_gpu(llr), msg_init=(g1["msg_x"], g1["msg_z"]),
@@ -346,7 +346,7 @@ def test_exact_shortcuts_on_runtime_degree_graphs(name, p, iters, factor, launch
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, p, B, first=99)
     gg = gpu_graph(name)
     L0 = llr_const(0.1)
-    o = oracle_graph(name).bp4_decode(sx, sz, iters, "boxplus-phi", factor, llr_const=L0, return_msgs=True)
+    o = oracle_library_forms(name).bp4_decode(sx, sz, iters, "boxplus-phi", factor, llr_const=L0, return_msgs=True)
     try:
         if launch == "generic":
             gg.force_generic(True)
@@ -360,7 +360,7 @@ def test_exact_shortcuts_on_runtime_degree_graphs(name, p, iters, factor, launch
         gg.set_saturation_shortcut(True)
         gg.set_fixed_point_exit(True)
         for cn in ("minsum", "boxplus"):  # the qubit-side shortcut also runs under the other rules
-            o2 = oracle_graph(name).bp4_decode(sx, sz, 12, cn, 0.8, llr_const=L0, return_msgs=True)
+            o2 = oracle_library_forms(name).bp4_decode(sx, sz, 12, cn, 0.8, llr_const=L0, return_msgs=True)
             _assert_bp_equal(o2, gg.bp4_decode(tx, tz, 12, cn, 0.8, llr_const=L0, return_msgs=True), f"{name} {cn}")
     finally:
         gg.force_generic(False)
@@ -384,7 +384,7 @@ def test_gnn_bp4_bit_exact(name, B, iters):
     """GNN_BP4 (BASELINE configs[4]) kernel vs the oracle: embeddings-derived LLRs, soft syndromes of every iteration
     and hard decisions, exactly."""
     from feedback_gnn_amd.graph import GnnBp4Weights
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, 0.05, B)
     w = _gnnbp4_weights()
     o = og.gnn_bp4(w, sx, sz, iters)
@@ -401,7 +401,7 @@ def test_gnn_bp4_class_contract():
                     activation="tanh", use_bias=True)
     w = _gnnbp4_weights(3)
     dec.set_weights(w)
-    og = oracle_graph("gb48")
+    og = oracle_library_forms("gb48")
     ex, ez = og.pauli_noise(SEED, 0.05, 0, 7)
     sx, sz = og.syndrome(ex, ez)
     llr_hat, x_hat, z_hat = dec((to_gpu(sx.astype(np.int64)), to_gpu(sz.astype(np.int64))))
@@ -444,7 +444,7 @@ def test_general_gnn_bp4_bit_exact(name, cfg):
     reduce ops, all four activations, bias on / off, trainable node and edge attributes) against the oracle's og_gnn_bp4_general,
     exactly; on the benchmark setting it also equals the specialised kernels in the literal association."""
     from feedback_gnn_amd.graph import GnnBp4Weights
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     B, iters = (4, 3) if name == "ghp882" else (11, 4)
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, 0.06, B, first=17)
     w = _gnnbp4_gen_weights(gg, cfg)
@@ -476,7 +476,7 @@ def test_general_gnn_bp4_class_surface():
     assert len(w0) == (7 * 3 + 1) * 2 + 7 and np.all(w0[42] == 0) and np.all(w0[43] == 1) and all(np.all(a == 0) for a in w0[44:])
     w = _gnnbp4_gen_weights(dec.graph, cfg, seed=5)
     dec.set_weights(w)
-    og = oracle_graph("gb48")
+    og = oracle_library_forms("gb48")
     ex, ez = og.pauli_noise(SEED, 0.05, 0, 6)
     sx, sz = og.syndrome(ex, ez)
     llr_hat, x_hat, z_hat = dec((to_gpu(sx.astype(np.int64)), to_gpu(sz.astype(np.int64))))
@@ -489,7 +489,7 @@ def test_general_gnn_bp4_class_surface():
 def test_gnn_bp4_mfma_and_valu_kernels_agree():
     from feedback_gnn_amd.graph import GnnBp4Weights
     name, B, iters = "ghp882", 5, 3
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, 0.05, B, first=9)
     w = _gnnbp4_weights(21)
     o = og.gnn_bp4(w, sx, sz, iters)
@@ -517,7 +517,7 @@ def test_gnn_bp4_mfma_and_valu_kernels_agree():
 def test_binary_syndrome_bp_bit_exact(name, cn_type, factor):
     """LDPCBPDecoder(is_syndrome=True) on hx (decoding.py:874-1048) — kernel vs oracle, soft logits and hard decisions."""
     B = 37
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     e = og.bsc_noise(SEED, 0.04, 0, B)
     ge = gg.bsc_noise(SEED, 0.04, 0, B)
     assert np.array_equal(e, ge.cpu().numpy())
@@ -585,7 +585,7 @@ def test_osd0_bit_exact_and_solves_the_syndrome(name, p):
     """OSD-0 (bp_osd.py:14-77) on the BP failures: kernel vs oracle, and H e_hat = syndrome for every processed sample."""
     c = code(name)
     B = 256
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, p, B, first=5)
     L0 = llr_const(p)
     o = og.bp4_decode(sx, sz, 30, "minsum", 0.8, llr_const=L0)
@@ -661,7 +661,7 @@ def test_overcomplete_irregular_graph():
 
     c = cq.css_code(overcomplete(base.hx, 150), overcomplete(base.hz, 130), name="gb48_oc")
     assert c.K == base.K and len(set(c.hx.sum(1))) > 2 and c.hx.sum(0).max() > 20
-    og, gg = OracleGraph(c), TannerGraph(c)
+    og, gg = OracleGraph(c, forms="library-default"), TannerGraph(c)
     assert gg.info()["regular"] == 0
     ex, ez = og.pauli_noise(SEED, 0.06, 0, 50)
     sx, sz = og.syndrome(ex, ez)
@@ -683,7 +683,7 @@ def test_north_star_full_size_properties_and_strided_oracle_check():
     from feedback_gnn_amd.graph import GnnWeights
     from feedback_gnn_amd.weights_io import read_weight_list
     name, B, p = "ghp882", 65536, 0.01
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     c = code(name)
     w = read_weight_list(WEIGHTS_882)
     gw = GnnWeights(w, gg.device)
@@ -736,7 +736,7 @@ def test_config3_full_shard_properties_and_strided_oracle_check():
     from feedback_gnn_amd.graph import GnnWeights
     from feedback_gnn_amd.weights_io import read_weight_list
     name, B, p = "ghp1270", 32768, 0.05
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     c = code(name)
     w = read_weight_list(WEIGHTS_1270)
     gw = GnnWeights(w, gg.device)
@@ -787,7 +787,7 @@ def test_config4_full_shard_gnn_bp4_properties_and_strided_oracle_check():
     gives permuted results; (iii) the decoder is a function of the syndrome alone: duplicated syndromes give duplicated rows."""
     from feedback_gnn_amd.graph import GnnBp4Weights
     name, B, iters = "ghp1270", 16384, 10
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     w = _gnnbp4_weights(5)
     gw = GnnBp4Weights(w, gg.device)
     ex, ez = gg.pauli_noise(SEED, 0.05, 7 * B, B)
@@ -816,10 +816,10 @@ def test_reference_overcomplete_codes_bit_exact(name, cn_type):
     B = 37
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, 0.08, B)
     L0 = llr_const(0.3)
-    o = oracle_graph(name).bp4_decode(sx, sz, 6, cn_type, 1.0, llr_const=L0, return_msgs=True)
+    o = oracle_library_forms(name).bp4_decode(sx, sz, 6, cn_type, 1.0, llr_const=L0, return_msgs=True)
     g = gpu_graph(name).bp4_decode(tx, tz, 6, cn_type, 1.0, llr_const=L0, return_msgs=True)
     _assert_bp_equal(o, g, f"{name} {cn_type}")
-    s0, l0, f0 = oracle_graph(name).residual(ex, ez, o["x_hat"], o["z_hat"])
+    s0, l0, f0 = oracle_library_forms(name).residual(ex, ez, o["x_hat"], o["z_hat"])
     s1, l1, f1 = gpu_graph(name).residual(gx, gz, g["x_hat"], g["z_hat"])
     assert np.array_equal(s0, s1.cpu().numpy()) and np.array_equal(l0, l1.cpu().numpy()) and np.array_equal(f0, f1.cpu().numpy())
 
@@ -878,7 +878,7 @@ def test_general_feedback_gnn_bit_exact(name, cfg):
     """Feedback_GNN with any constructor setting (fgnn_weights_create_general, runtime-shaped kernel) against the oracle."""
     from feedback_gnn_amd.graph import GnnWeights
     B = 21
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     (ex, ez, sx, sz), (gx, gz, tx, tz) = _noise_and_syndromes(name, 0.08, B)
     o = og.bp4_decode(sx, sz, 6, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
     w = _gen_weights(cfg)
@@ -908,7 +908,7 @@ def test_general_feedback_gnn_in_the_sandwich_and_class_surface():
     name, B, p = "ghp882", 64, 0.11
     cfg = (8, 16, 3, "max", "relu", True)
     c = code(name)
-    og, gg = oracle_graph(name), gpu_graph(name)
+    og, gg = oracle_library_forms(name), gpu_graph(name)
     G = Feedback_GNN(code=c, num_msg_dims=8, num_hidden_units=16, num_mlp_layers=3, reduce_op="max", activation="relu",
                      use_bias=True, graph=gg)
     assert not G.is_shipped_architecture and G.count_params() == sum(int(np.prod(a.shape)) for a in G.get_weights())
@@ -1005,7 +1005,7 @@ def test_random_codes_fuzz_every_runtime_degree_kernel():
         if c.K == 0:
             continue  # css_code derives no logical operators: GNN_BP4's logical rows would be empty — covered by the other 12
         done += 1
-        og, gg = OracleGraph(c), TannerGraph(c)
+        og, gg = OracleGraph(c, forms="library-default"), TannerGraph(c)
         B = int(rng.randint(1, 40))
         ex, ez = og.pauli_noise(SEED, 0.07, 100 * done, B)
         sx, sz = og.syndrome(ex, ez)

@@ -56,15 +56,15 @@ def test_eight_ranks_shard_the_sample_stream_and_reduce_like_bench(tmp_path):
     import json
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import llr_const, oracle_graph
+    from helpers import llr_const, oracle_library_forms
     B, K, W, P, SEED = 24, 2, 1, 0.09, 0x5EED
     script = _script(tmp_path, f"""
         import os, sys, time, json, numpy as np, torch, torch.distributed as dist
         sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "tests"))
-        from helpers import llr_const, oracle_graph
+        from helpers import llr_const, oracle_library_forms
         rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        g = oracle_graph("gb48")
+        g = oracle_library_forms("gb48")
         nxt, counts = 0, np.zeros(3, np.int64)
         t0 = time.perf_counter()
         for step in range({W} + {K}):
@@ -89,7 +89,7 @@ def test_eight_ranks_shard_the_sample_stream_and_reduce_like_bench(tmp_path):
     assert codes == [0] * 8
     d = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
     assert d["world"] == 8 and len(d["per_rank"]) == 8 and abs(max(d["per_rank"]) - d["max"]) < 1e-12
-    g = oracle_graph("gb48")
+    g = oracle_library_forms("gb48")
     lo, n = W * 8 * B, K * 8 * B  # the timed steps cover global samples [W*8B, (W+K)*8B)
     ex, ez = g.pauli_noise(SEED, P, lo, n)
     sx, sz = g.syndrome(ex, ez)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from feedback_gnn_amd.weights_io import read_weight_list
-from helpers import WEIGHTS_1270, WEIGHTS_882, code, llr_const, oracle_graph
+from helpers import WEIGHTS_1270, WEIGHTS_882, code, llr_const, oracle_library_forms
 from oracle import numpy_ref as R
 
 SEED = 0x5EED
@@ -12,7 +12,7 @@ LLR_TOL = 1e-4  # north-star tolerance on LLRs
 
 
 def _setup(name, p, B, first=0):
-    g = oracle_graph(name)
+    g = oracle_library_forms(name)
     ex, ez = g.pauli_noise(SEED, p, first, B)
     sx, sz = g.syndrome(ex, ez)
     return g, ex, ez, sx, sz
@@ -168,7 +168,7 @@ def _gnnbp4_weights(seed=11):
 @pytest.mark.parametrize("name", ["gb48", "rsurf5"])
 def test_gnn_bp4_oracle_vs_numpy_restatement(name):
     """GNN_BP4 (gnn.py:383-423, repaired): C oracle (fmaf chains, polynomial tanh) vs NumPy matmul restatement."""
-    g = oracle_graph(name)
+    g = oracle_library_forms(name)
     ex, ez = g.pauli_noise(SEED, 0.05, 0, 12)
     sx, sz = g.syndrome(ex, ez)
     w = _gnnbp4_weights()
@@ -188,7 +188,7 @@ def test_torch_float64_restatement_matches_oracle_forward():
     from oracle import torch_ref as T
     name = "gb48"
     c = code(name)
-    g = oracle_graph(name)
+    g = oracle_library_forms(name)
     ex, ez = g.pauli_noise(SEED, 0.05, 0, 6)
     sx, sz = g.syndrome(ex, ez)
     rng = np.random.RandomState(1)
@@ -221,7 +221,7 @@ def test_general_feedback_gnn_oracle_equals_specialised_on_the_shipped_setting()
     """og_feedback_gnn_general (always the literal association: it serves every reduce_op) with (20, 40, 2, mean, tanh, bias) walks
     the same float ops as og_feedback_gnn in the literal order; the factored order (the default) is the same function with other
     roundings."""
-    g = oracle_graph("gb48")
+    g = oracle_library_forms("gb48")
     ex, ez = g.pauli_noise(SEED, 0.06, 0, 9)
     sx, sz = g.syndrome(ex, ez)
     o = g.bp4_decode(sx, sz, 5, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
@@ -246,7 +246,7 @@ def test_general_feedback_gnn_oracle_vs_float64_restatement(cfg):
     from oracle import torch_ref as T
     name = "rsurf5"  # irregular degrees: qubits with 1 or 2 checks per side, so sum / mean / max / min all differ
     c = code(name)
-    g = oracle_graph(name)
+    g = oracle_library_forms(name)
     ex, ez = g.pauli_noise(SEED, 0.08, 0, 5)
     sx, sz = g.syndrome(ex, ez)
     o = g.bp4_decode(sx, sz, 4, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
@@ -272,7 +272,7 @@ def _rand_weights(shapes, seed):
 def test_general_gnn_bp4_oracle_equals_specialised_on_the_benchmark_setting():
     """og_gnn_bp4_general with (20, 40, 2, mean, tanh, bias, no attributes) walks the float ops of og_gnn_bp4 in the literal order."""
     from oracle import numpy_ref as R
-    g, c = oracle_graph("gb48"), code("gb48")
+    g, c = oracle_library_forms("gb48"), code("gb48")
     ex, ez = g.pauli_noise(SEED, 0.05, 0, 9)
     sx, sz = g.syndrome(ex, ez)
     cfg = (20, 40, 2, 1, 1, 1, 0, 0, 0)
@@ -294,7 +294,7 @@ def test_general_gnn_bp4_oracle_vs_numpy_restatement(name, cfg):
     """Every constructor setting of GNN_BP4 (widths, depth, reduce op, activation, bias, node / edge attributes in the reference's
     np.where edge order): the C oracle against the batch-first NumPy restatement (NumPy's matmul, reduceat and activations)."""
     from oracle import numpy_ref as R
-    g, c = oracle_graph(name), code(name)
+    g, c = oracle_library_forms(name), code(name)
     ex, ez = g.pauli_noise(SEED, 0.06, 0, 5)
     sx, sz = g.syndrome(ex, ez)
     w = _rand_weights(R.gnn_bp4_general_shapes(c, cfg), 3)

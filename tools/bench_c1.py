@@ -9,7 +9,7 @@ from helpers import code, llr_const
 from feedback_gnn_amd.graph import TannerGraph
 from oracle.oracle import OracleGraph, num_threads
 B, P, IT = 256, 0.05, 32
-c = code('ghp882'); og = OracleGraph(c); gg = TannerGraph(c)
+c = code('ghp882'); og = OracleGraph(c, forms="library-default"); gg = TannerGraph(c)
 out = {"config": "[[882,24]] BP4 32 iterations, batch 256, p=0.05 (BASELINE.json configs[0])", "cpu_threads": num_threads()}
 for cn, fac in (("boxplus", 0.625), ("boxplus-phi", 0.625)):
     # GPU first: the oracle's OpenMP threads keep spinning for a while after a parallel region and would slow the launch loop

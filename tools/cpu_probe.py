@@ -10,7 +10,7 @@ for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
 import helpers as H
 from oracle import torch_cpu_baseline as T
 from feedback_gnn_amd.weights_io import read_weight_list
-og=H.oracle_graph('ghp882'); w=read_weight_list(H.WEIGHTS_882); L0=H.llr_const(0.05)
+og=H.oracle_library_forms('ghp882'); w=read_weight_list(H.WEIGHTS_882); L0=H.llr_const(0.05)
 tg=T.Graph(H.code('ghp882'))
 torch.set_flush_denormal(True)
 for B in (256, 1024):

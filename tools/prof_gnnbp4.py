@@ -2,12 +2,12 @@
 import sys, torch, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from helpers import code
-from feedback_gnn_amd.graph import TannerGraph, GnnBp4Weights, GNNBP4_SHAPES
+from feedback_gnn_amd.graph import TannerGraph, GnnBp4Weights
+from bench import gnnbp4_seeded_weights  # the weights bench.py --config c5 times
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384  # BASELINE configs[4]: 131 072 / 8 GPUs
 g = TannerGraph(code('ghp1270'))
-rng = np.random.RandomState(0)
-w = GnnBp4Weights([rng.uniform(-0.3, 0.3, size=s).astype(np.float32) for s in GNNBP4_SHAPES], g.device)
-ex, ez = g.pauli_noise(0x5EED, 0.05, 0, B); sx, sz = g.syndrome(ex, ez)
+w = GnnBp4Weights(gnnbp4_seeded_weights(0), g.device)
+ex, ez = g.pauli_noise(0x5EED, 0.01, 0, B); sx, sz = g.syndrome(ex, ez)
 for _ in range(2):
     g.gnn_bp4_decode(w, sx, sz, 10, return_logits=False)
 torch.cuda.synchronize(); print("done")

@@ -1,5 +1,5 @@
 """Launch each hot kernel a few times at the benchmark shape (for rocprofv3 --kernel-trace / --pmc passes).
-    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU ... -d out -- python3 tools/prof_kernels.py [code] [B] [fixed|product]
+    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU ... -d out -- python3 tools/prof_kernels.py [code] [B] [fixed|product] [iters, e.g. 64,16]
 `fixed` (default) switches the exact shortcuts off, like bench.py's headline: every exp/log of every iteration is evaluated."""
 import sys
 import torch
@@ -9,6 +9,7 @@ from feedback_gnn_amd.graph import TannerGraph, GnnWeights
 from feedback_gnn_amd.weights_io import read_weight_list
 name = sys.argv[1] if len(sys.argv) > 1 else 'ghp882'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+ITERS = [int(x) for x in sys.argv[4].split(',')] if len(sys.argv) > 4 else [64, 16]
 g = TannerGraph(code(name))
 g.set_saturation_shortcut(len(sys.argv) > 3 and sys.argv[3] == 'product')
 import os
@@ -21,9 +22,9 @@ sx, sz = g.syndrome(ex, ez)
 L0 = llr_const(0.05)
 w = GnnWeights(read_weight_list(WEIGHTS_882 if name == 'ghp882' else WEIGHTS_1270), g.device)
 for _ in range(2):
-    o = g.bp4_decode(sx, sz, 64, "boxplus-phi", 1.0, llr_const=L0)
+    o = g.bp4_decode(sx, sz, ITERS[0], "boxplus-phi", 1.0, llr_const=L0)
     nl = g.feedback_gnn(w, o['llr'], o['z_logit'], o['x_logit'], sx, sz)
-    o2 = g.bp4_decode(sx, sz, 16, "boxplus-phi", 1.0, llr_ch=nl)
+    o2 = g.bp4_decode(sx, sz, ITERS[1], "boxplus-phi", 1.0, llr_ch=nl)
     g.residual(ex, ez, o2['x_hat'], o2['z_hat'])
 torch.cuda.synchronize()
 print("done")

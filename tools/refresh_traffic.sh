@@ -1,18 +1,33 @@
 #!/bin/bash
-# Re-measure what bench.py's roofline quotes from profiles/traffic.json (HBM bytes, VALU / MFMA instruction counts per launch of the
-# BP4-64 and feedback-GNN kernels at the benchmark shape) after a kernel source changed:   bash tools/refresh_traffic.sh <tag>
-# Three rocprofv3 --pmc passes (~20 s each) on the GPU box; copies the summary and the regenerated traffic.json into gpurun_out/<tag>/
-# (then: cp gpurun_out/<tag>/traffic.json profiles/traffic.json; cp gpurun_out/<tag>/pmc_summary.txt profiles/<tag>_pmc_summary.txt).
+# Re-measure what bench.py's rooflines quote from profiles/traffic.json (HBM bytes, VALU / MFMA instruction counts per launch of the
+# dominant kernels of BASELINE configs[2], [3] and [4] at their per-GPU shard shapes) after a kernel source changed:
+#     bash tools/refresh_traffic.sh <tag> [c3 c4 c5]
+# Four rocprofv3 --pmc passes per configuration (~20-40 s each) on the GPU box; writes the summaries and the regenerated traffic.json into
+# gpurun_out/<tag>/ (then: cp gpurun_out/<tag>/traffic.json profiles/traffic.json; cp gpurun_out/<tag>/*pmc_summary.txt profiles/).
 set -e
 TAG=${1:-r00}
+shift || true
+CONFIGS=${@:-c3 c4 c5}
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
-  tag=$(echo $set | cut -d' ' -f1)
-  timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $O/pmc_$tag -- python3 tools/prof_kernels.py ghp882 65536 fixed > $O/pmc_$tag.log 2>&1
+SETS=("FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY")
+SPECS=""
+for cfg in $CONFIGS; do
+  case $cfg in
+    c3) PROG="tools/prof_kernels.py ghp882 65536 fixed 64,16"; SPEC="sandwich:ghp882:65536:64";;
+    c4) PROG="tools/prof_kernels.py ghp1270 32768 fixed 64,64"; SPEC="sandwich:ghp1270:32768:64";;
+    c5) PROG="tools/prof_gnnbp4.py 16384"; SPEC="gnnbp4:ghp1270:16384:10";;
+    *) echo "unknown config $cfg"; exit 1;;
+  esac
+  for set in "${SETS[@]}"; do
+    tag=$(echo $set | cut -d' ' -f1)
+    timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/${cfg}_pmc_$tag -- python3 $PROG > $O/${cfg}_pmc_$tag.log 2>&1
+    echo "$cfg $tag done"
+  done
+  python tools/pmc_summary.py $O/${cfg}_pmc_*/*/*_counter_collection.csv > $O/${cfg}_pmc_summary.txt
+  SPECS="$SPECS $SPEC=$O/${cfg}_pmc_summary.txt"
 done
-python tools/pmc_summary.py $O/pmc_*/*/*_counter_collection.csv > $O/pmc_summary.txt
-python tools/make_traffic_json.py $O/pmc_summary.txt "$TAG" > $O/traffic.json
-grep -E "(bp4_kernel|gnn_mfma_kernel).* (FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU |SQ_INSTS_MFMA|GRBM_GUI_ACTIVE)" $O/pmc_summary.txt || true
+python tools/make_traffic_json.py "$TAG" $SPECS > $O/traffic.json
+grep -E "(bp4_kernel|gnn_stream_kernel|gnn_bp4).* (FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU |SQ_INSTS_MFMA|GRBM_GUI_ACTIVE)" $O/c*_pmc_summary.txt || true
