@@ -25,6 +25,7 @@ constexpr int D = 20;
 constexpr int H = 40;
 
 struct MlpDev {
+    const float* w1;   // [nin][H]      (W1 as Keras holds it, 32-byte aligned: row k = the weights input k feeds; gnn_bp4_stream_kernel)
     const float* w1t;  // [H][nin_pad]  (W1 transposed; row j = the weights of hidden unit j)
     const float* b1;   // [H]
     const float* w2;   // [H][D]
@@ -624,6 +625,355 @@ gnn_bp4_mfma_kernel(GraphDev g, GnnBp4Dev w, Args a, int tab_floats, int residen
 }
 
 // ---------------------------------------------------------------------------------------------
+// Streaming path (degree-regular graphs, FGNN_OPT_GNN_STREAM): no MFMA, no operand tables.  One lane per receiving node, the node's
+// vectors in registers, every weight a wave-uniform scalar — and every multiply-add a v_pk_fma_f32: TWO hidden units (or two output
+// elements) per instruction, the weights of the pair as one SGPR pair, the per-lane input broadcast to both halves by op_sel.  On
+// gfx950 that instruction issues in the time of ONE SGPR-operand v_fmac (tools/microbench: 1.85-1.93 ns per wave-instruction and SIMD
+// against 1.79), i.e. the uniform-weight multiply-adds run at the full f32 rate of 64 FLOP per clock and SIMD — the rate of the
+// f32 MFMA — without the MFMA tiles' padding of 40-, 20- and 3-row outputs to multiples of 16 (76 % useful rows in this layer stack).
+// A Dense layer runs k-outer / j-inner: for input k = 0, 1, ... one packed fma per PAIR of output units continues that pair's chain,
+// so every output sees fmaf(in[k], W[k][j], acc) in ascending k from the oracle's start value — the oracle's bits — while consecutive
+// instructions are independent (no packed-math dependency stalls).  Hidden units are walked in five blocks of eight (four pairs): the
+// block's first-layer accumulators, its tanh values and the 20 second-layer accumulators they stream into are all that is live.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef const f2 __attribute__((address_space(4)))* scalar_f2p;
+__device__ __forceinline__ scalar_f2p as_scalar2(const float* p) { return (scalar_f2p)(unsigned long long)p; }
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 bc2(float x) { return f2{x, x}; }
+
+constexpr int HB = 8, HBP = HB / 2, NHB = H / HB;  // hidden units per block, pairs per block, blocks
+constexpr int DP = D / 2;                          // an embedding / message vector as pairs of consecutive elements
+static_assert(H % HB == 0 && D % 4 == 0, "block / pair structure of the streaming GNN_BP4 kernel");
+
+// acc[jp] = fmaf(in[k], W[k][j0 + 2 jp + {0, 1}], acc[jp]) for k = 0 .. K-1 in this order; the K inputs arrive as (K + 1) / 2 pairs of
+// consecutive elements (element k = half k & 1 of pair k >> 1, picked by the instruction's op_sel: no broadcast copies); w = &W[0][j0],
+// row stride in floats.  The weight rows arrive through the scalar cache in groups of KG rows, one group ahead: scalar loads return
+// out of order, so the only wait there is is "all of them" (s_waitcnt lgkmcnt(0)); the group in use is therefore waited for FIRST (the
+// empty asm that names it), then the next group's loads are issued, then the group's packed fmas run — and the scheduler may not move
+// anything across the group boundaries (left alone it hoists every s_load of a layer to the top and spills hundreds of SGPRs).  The
+// input pairs pass through an empty asm at the top: a loop-invariant input would otherwise have its {x, x} broadcasts hoisted out of
+// the caller's block loop as twice as many live registers.
+template <int K, int JP, int KG>
+__device__ __forceinline__ void dense_pk(const f2 (&in2)[(K + 1) / 2], const float* w, int stride, f2 (&acc)[JP])
+{
+    constexpr int NG = (K + KG - 1) / KG, KP = (K + 1) / 2;
+    f2 x[KP];
+#pragma unroll
+    for (int q = 0; q < KP; ++q) {
+        x[q] = in2[q];
+        asm volatile("" : "+v"(x[q]));
+    }
+    f2 buf[2][KG][JP];
+#pragma unroll
+    for (int kk = 0; kk < KG; ++kk)
+        if (kk < K) {
+            scalar_f2p r = as_scalar2(w + kk * stride);
+#pragma unroll
+            for (int jp = 0; jp < JP; ++jp) buf[0][kk][jp] = r[jp];
+        }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        asm volatile("" ::"s"(buf[g & 1][0][0]));  // the group's rows are in their SGPRs from here on
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int kk = 0; kk < KG; ++kk)
+                if ((g + 1) * KG + kk < K) {
+                    scalar_f2p r = as_scalar2(w + ((g + 1) * KG + kk) * stride);
+#pragma unroll
+                    for (int jp = 0; jp < JP; ++jp) buf[(g + 1) & 1][kk][jp] = r[jp];
+                }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KG; ++kk)
+            if (g * KG + kk < K) {
+                const int k = g * KG + kk;
+                const f2 pr = x[k >> 1];
+                const f2 xb = (k & 1) ? __builtin_shufflevector(pr, pr, 1, 1) : __builtin_shufflevector(pr, pr, 0, 0);
+#pragma unroll
+                for (int jp = 0; jp < JP; ++jp) acc[jp] = pk_fma(xb, buf[g & 1][kk][jp], acc[jp]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+constexpr int KG1 = 4;  // first-layer rows (8 floats of a block) per group: 2 x 32 SGPRs in flight
+constexpr int KG2 = 1;  // last-layer rows (20 floats) per group: 2 x 20 SGPRs
+
+__device__ __forceinline__ void load_row20(const float* row, f2 (&r)[DP])
+{
+    const float4* p = reinterpret_cast<const float4*>(row);
+#pragma unroll
+    for (int q = 0; q < D / 4; ++q) {
+        const float4 v = p[q];
+        r[2 * q] = f2{v.x, v.y};
+        r[2 * q + 1] = f2{v.z, v.w};
+    }
+}
+__device__ __forceinline__ void store_row20(float* row, const f2 (&r)[DP])
+{
+    float4* p = reinterpret_cast<float4*>(row);
+#pragma unroll
+    for (int q = 0; q < D / 4; ++q) p[q] = make_float4(r[2 * q].x, r[2 * q].y, r[2 * q + 1].x, r[2 * q + 1].y);
+}
+__device__ __forceinline__ f2 tanh2(f2 a) { return f2{fg_tanh(a.x), fg_tanh(a.y)}; }
+
+// A whole two-layer MLP (oracle: mlp2) on a register vector of NIN elements: out = tanh(in W1 + b1) W2 + b2, hidden units in blocks of eight.
+template <int NIN>
+__device__ __forceinline__ void mlp_stream(const f2 (&in2)[(NIN + 1) / 2], const MlpDev& m, f2 (&out)[DP])
+{
+#pragma unroll
+    for (int i = 0; i < DP; ++i) out[i] = bc2(0.0f);
+#pragma unroll 1
+    for (int blk = 0; blk < NHB; ++blk) {
+        f2 t[HBP];
+#pragma unroll
+        for (int jp = 0; jp < HBP; ++jp) t[jp] = bc2(0.0f);
+        dense_pk<NIN, HBP, KG1>(in2, m.w1 + blk * HB, H, t);
+        scalar_f2p b1 = as_scalar2(m.b1 + blk * HB);
+        f2 h[HBP];
+#pragma unroll
+        for (int jp = 0; jp < HBP; ++jp) h[jp] = tanh2(t[jp] + b1[jp]);
+        dense_pk<HB, DP, KG2>(h, m.w2 + blk * HB * D, D, out);
+    }
+    scalar_f2p b2 = as_scalar2(m.b2);
+#pragma unroll
+    for (int i = 0; i < DP; ++i) out[i] = out[i] + b2[i];
+}
+
+// The message MLP + (signed) mean of one receiving node and side in the FACTORED association (oracle: msg_mean_factored) for a node
+// of DEG edges: nbr(e, sg) = the embedding row of edge e's other end and its sign +-1.  Per block of eight hidden units: pb = own
+// W1[D:2D] + b1 once, every edge continues pb over its neighbour row, tanh, signed sum; the block's eight sums stream into the ONE last
+// Dense.  The edge loop is a real loop with the next edge's row requested one edge ahead (an L2-resident row of another lane's making).
+template <int DEG, bool SIGNED, typename NbrFn>
+__device__ __forceinline__ void msg_side_stream(const f2 (&own)[DP], NbrFn nbr, const MlpDev& m, f2 (&mean)[DP])
+{
+#pragma unroll
+    for (int i = 0; i < DP; ++i) mean[i] = bc2(0.0f);
+    float S = 0.0f;
+#pragma unroll 1
+    for (int blk = 0; blk < NHB; ++blk) {
+        f2 pb[HBP];
+#pragma unroll
+        for (int jp = 0; jp < HBP; ++jp) pb[jp] = bc2(0.0f);
+        dense_pk<D, HBP, KG1>(own, m.w1 + D * H + blk * HB, H, pb);
+        scalar_f2p b1 = as_scalar2(m.b1 + blk * HB);
+#pragma unroll
+        for (int jp = 0; jp < HBP; ++jp) pb[jp] = pb[jp] + b1[jp];
+        f2 hs[HBP];
+#pragma unroll
+        for (int jp = 0; jp < HBP; ++jp) hs[jp] = bc2(0.0f);
+        f2 src[DP];
+        float sg;
+        load_row20(nbr(0, sg), src);
+#pragma unroll 1
+        for (int e = 0; e < DEG; ++e) {
+            f2 nxt[DP];
+            float sgn = 1.0f;
+            if (e + 1 < DEG) load_row20(nbr(e + 1, sgn), nxt);
+            f2 t[HBP];
+#pragma unroll
+            for (int jp = 0; jp < HBP; ++jp) t[jp] = pb[jp];
+            dense_pk<D, HBP, KG1>(src, m.w1 + blk * HB, H, t);
+#pragma unroll
+            for (int jp = 0; jp < HBP; ++jp) {
+                const f2 h = tanh2(t[jp]);
+                // oracle: h sg, then first ? that : acc + that.  h sg is exact (sg = +-1), so the fma rounds once like the add
+                const f2 first = SIGNED ? h * bc2(sg) : h;
+                const f2 later = SIGNED ? pk_fma(h, bc2(sg), hs[jp]) : hs[jp] + h;
+                hs[jp] = (e == 0) ? first : later;
+            }
+            S = (e == 0) ? sg : S + sg;
+#pragma unroll
+            for (int i = 0; i < DP; ++i) src[i] = nxt[i];
+            sg = sgn;
+        }
+        dense_pk<HB, DP, KG2>(hs, m.w2 + blk * HB * D, D, mean);
+    }
+    scalar_f2p b2 = as_scalar2(m.b2);
+    const float fd = (float)DEG;
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
+        const f2 o = pk_fma(b2[i], bc2(S), mean[i]);
+        mean[i] = f2{o.x / fd, o.y / fd};
+    }
+}
+
+// The same in the LITERAL association: one whole message MLP per edge, (signed) sum, / DEG.
+template <int DEG, bool SIGNED, typename NbrFn>
+__device__ __forceinline__ void msg_side_literal(const f2 (&own)[DP], NbrFn nbr, const MlpDev& m, f2 (&mean)[DP])
+{
+#pragma unroll
+    for (int i = 0; i < DP; ++i) mean[i] = bc2(0.0f);
+#pragma unroll 1
+    for (int e = 0; e < DEG; ++e) {
+        f2 feat[D], msg[DP];
+        float sg;
+        {
+            f2 src[DP];
+            load_row20(nbr(e, sg), src);
+#pragma unroll
+            for (int i = 0; i < DP; ++i) { feat[i] = src[i]; feat[DP + i] = own[i]; }
+        }
+        mlp_stream<2 * D>(feat, m, msg);
+#pragma unroll
+        for (int i = 0; i < DP; ++i) {
+            const f2 mv = SIGNED ? msg[i] * bc2(sg) : msg[i];
+            mean[i] = (e == 0) ? mv : mean[i] + mv;
+        }
+    }
+    const float fd = (float)DEG;
+#pragma unroll
+    for (int i = 0; i < DP; ++i) mean[i] = f2{mean[i].x / fd, mean[i].y / fd};
+}
+
+// one of two weight sets by a wave-uniform index, field by field (scalar selects: indexing the by-value kernel argument with a loop
+// counter would send the struct through private memory and the pointers through VGPRs)
+__device__ __forceinline__ MlpDev pick_mlp(const MlpDev& a, const MlpDev& b, int which)
+{
+    MlpDev m;
+    m.w1 = which ? b.w1 : a.w1;
+    m.w1t = which ? b.w1t : a.w1t;
+    m.b1 = which ? b.b1 : a.b1;
+    m.w2 = which ? b.w2 : a.w2;
+    m.b2 = which ? b.b2 : a.b2;
+    return m;
+}
+
+#ifndef FGNN_GNNBP4_STREAM_WAVES
+#define FGNN_GNNBP4_STREAM_WAVES 3  // waves per SIMD the registers are budgeted for (168 VGPRs: own, two means, a block's state, two rows)
+#endif
+template <int DV, int DC, bool FACT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FGNN_GNNBP4_STREAM_WAVES, FGNN_GNNBP4_STREAM_WAVES)))
+gnn_bp4_stream_kernel(GraphDev g, GnnBp4Dev w, Args a)
+{
+    FG_LOG_TAB_SETUP();
+    extern __shared__ float lds[];
+    constexpr int T = 256;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = g.n, mx = g.m_x, mz = g.m_z, m = g.m;
+    float* lx = lds;       // [n] llr_x of cal_logit
+    float* lz = lx + n;    // [n] llr_z
+    float* hlog = lz + n;  // [m] hx_logit then hz_logit
+    float* ssg = hlog + m; // [m] syndrome signs 1 - 2 s as floats
+    float* hv = a.work + (size_t)b * (size_t)(n + m) * D;  // rows in natural element order (private to this kernel)
+    float* hc = hv + (size_t)n * D;
+    const uint8_t* sx = a.synd_x + (size_t)b * mx;
+    const uint8_t* sz = a.synd_z + (size_t)b * mz;
+    const int rxp = mz + g.rows[5], rzp = mx + g.rows[4];
+    for (int i = tid; i < n * D; i += T) hv[i] = 1.0f;  // (:396)
+    for (int i = tid; i < m * D; i += T) hc[i] = 0.0f;  // (:392-393)
+    for (int c = tid; c < m; c += T) {
+        hlog[c] = 0.0f;  // zero logits for the first CN update (:400-401)
+        ssg[c] = ((c < mx ? sx[c] : sz[c - mx]) & 1) ? -1.0f : 1.0f;
+    }
+    __syncthreads();
+    float* llr = a.llr_out + (size_t)b * 3 * n;
+    for (int it = -1; it < a.num_iter; ++it) {
+        if (it >= 0) {
+            // ---- UpdateVNEmbeddings (:714-751) + llr / binary LLRs of cal_logit (:291-304) ----
+            for (int v = tid; v < n; v += T) {
+                f2 feat3[3 * DP];
+                {
+                    f2 own[DP];
+                    load_row20(hv + (size_t)v * D, own);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        f2 mean[DP];
+                        const int* chk = g.vchk + (s ? g.E_x : 0) + v * DV;
+                        const int cbase = s ? mx : 0;
+                        auto nbr = [&](int e, float& sg) {
+                            const int c = cbase + chk[e];
+                            sg = ssg[c];
+                            return hc + (size_t)c * D;
+                        };
+                        if constexpr (FACT) msg_side_stream<DV, true>(own, nbr, w.vn_msg[s], mean);
+                        else msg_side_literal<DV, true>(own, nbr, w.vn_msg[s], mean);
+#pragma unroll
+                        for (int i = 0; i < DP; ++i) feat3[s * DP + i] = mean[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) feat3[2 * DP + i] = own[i];
+                }
+                f2 nh[DP];
+                mlp_stream<3 * D>(feat3, w.vn_embed, nh);
+                store_row20(hv + (size_t)v * D, nh);
+                f2 Lp[2] = {bc2(0.0f), bc2(0.0f)};
+                dense_pk<D, 2, 5>(nh, w.winv, 4, Lp);
+                const float L0 = Lp[0].x + as_scalar(w.binv)[0], L1 = Lp[0].y + as_scalar(w.binv)[1], L2 = Lp[1].x + as_scalar(w.binv)[2];
+                llr[v] = L0;
+                llr[n + v] = L1;
+                llr[2 * n + v] = L2;
+                lz[v] = fg_softplus(-L0) - fg_lse2(-L2, -L1);
+                lx[v] = fg_softplus(-L2) - fg_lse2(-L0, -L1);
+            }
+            __syncthreads();
+            // ---- soft syndromes (:306-314): hx rows use llr_z, hz rows use llr_x; logical rows appended ----
+            float* xl = a.xlog_all ? a.xlog_all + ((size_t)it * a.B + b) * rxp : nullptr;
+            float* zl = a.zlog_all ? a.zlog_all + ((size_t)it * a.B + b) * rzp : nullptr;
+            for (int c = tid; c < m; c += T) {
+                const int p0 = g.cptr[c];
+                const float vq = logit_row_gnn(c < mx ? lz : lx, g.cvn + p0, g.cptr[c + 1] - p0);
+                hlog[c] = vq;
+                if (c < mx) { if (zl) zl[c] = vq; }
+                else if (xl) xl[c - mx] = vq;
+            }
+            if (xl)
+                for (int r = tid; r < g.rows[5]; r += T)
+                    xl[mz + r] = logit_row_gnn(lx, g.rcol[5] + g.rptr[5][r], g.rptr[5][r + 1] - g.rptr[5][r]);
+            if (zl)
+                for (int r = tid; r < g.rows[4]; r += T)
+                    zl[mx + r] = logit_row_gnn(lz, g.rcol[4] + g.rptr[4][r], g.rptr[4][r + 1] - g.rptr[4][r]);
+            __syncthreads();
+            if (it == a.num_iter - 1) break;  // (:414-415)
+        }
+        // ---- UpdateCNEmbeddings (:573-610) ----
+        for (int c = tid; c < m; c += T) {
+            const int s = c >= mx;
+            f2 feat[DP + DP + 1];
+            {
+                f2 own[DP], mean[DP];
+                load_row20(hc + (size_t)c * D, own);
+                const int* vns = g.cvn + c * DC;
+                auto nbr = [&](int e, float& sg) {
+                    sg = 1.0f;
+                    return hv + (size_t)vns[e] * D;
+                };
+                // a wave of 64 checks may straddle the hx / hz boundary, and the two sides have their own weights: each side's update
+                // runs under its own lane mask with wave-uniform (scalar) weights; a wave that holds one side skips the other pass
+                // (readfirstlane: inside `s == ss` the compiler substitutes the per-lane s for the loop counter, and the weight
+                // pointers selected by it would travel through VGPRs and vector loads)
+#pragma unroll 1
+                for (int ss = 0; ss < 2; ++ss)
+                    if (s == ss) {
+                        const MlpDev mm = pick_mlp(w.cn_msg[0], w.cn_msg[1], __builtin_amdgcn_readfirstlane(ss));
+                        if constexpr (FACT) msg_side_stream<DC, false>(own, nbr, mm, mean);
+                        else msg_side_literal<DC, false>(own, nbr, mm, mean);
+                    }
+#pragma unroll
+                for (int i = 0; i < DP; ++i) { feat[i] = mean[i]; feat[DP + i] = own[i]; }
+            }
+            feat[2 * DP] = f2{(it >= 0) ? hlog[c] * ssg[c] : 0.0f, 0.0f};  // (:417-418)
+            f2 nh[DP];
+#pragma unroll 1
+            for (int ss = 0; ss < 2; ++ss)
+                if (s == ss) mlp_stream<2 * D + 1>(feat, pick_mlp(w.cn_embed[0], w.cn_embed[1], __builtin_amdgcn_readfirstlane(ss)), nh);
+            store_row20(hc + (size_t)c * D, nh);
+        }
+        __syncthreads();
+    }
+    for (int v = tid; v < n; v += T) {  // make_hard_decision (:359-367)
+        const float X = llr[v], Y = llr[n + v], Z = llr[2 * n + v];
+        int d = 0;
+        float best = 0.0f;
+        if (X < best) { best = X; d = 1; }
+        if (Z < best) { best = Z; d = 2; }
+        if (Y < best) { best = Y; d = 3; }
+        a.x_hat[(size_t)b * n + v] = (uint8_t)(d & 1);
+        a.z_hat[(size_t)b * n + v] = (uint8_t)(d >> 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Runtime-shaped GNN_BP4 (fgnn_gnnbp4_weights_create_general): any num_embed_dims / num_hidden_units / num_mlp_layers / reduce_op /
 // activation / use_bias / use_attributes setting the reference's classes accept (gnn.py:131-207, :494-751) within the limits of
 // fgnn.h.  One thread per receiving node, Dense = fmaf chain in ascending k from 0, (+ bias), activation — the oracle's
@@ -831,16 +1181,18 @@ extern "C" int fgnn_gnnbp4_weights_create(const float* const host_arrays[30], in
         if (!host_arrays[i]) return fgnn_fail(FGNN_ERR_ARG, "weight array is NULL");
     FGNN_DEVICE_GUARD(device);
     std::vector<float> h;
-    auto push = [&](size_t count) {
+    auto push = [&](size_t count) {  // offsets and sizes in multiples of 8 floats: every array starts 32-byte aligned
         size_t o = h.size();
-        h.resize(o + ((count + 3) & ~size_t(3)), 0.0f);
+        h.resize(o + ((count + 7) & ~size_t(7)), 0.0f);
         return o;
     };
     const int nin[7] = {2 * D, 2 * D, 2 * D + 1, 2 * D + 1, 2 * D, 2 * D, 3 * D};
     const int npad[7] = {2 * D, 2 * D, 2 * D + 4, 2 * D + 4, 2 * D, 2 * D, 3 * D};
-    size_t off[7][4];
+    size_t off[7][4], off_w1[7];
     for (int q = 0; q < 7; ++q) {
         const float* const* a = host_arrays + 4 * q;
+        off_w1[q] = push((size_t)nin[q] * H);  // [nin][H] as given: the streaming kernel's scalar pair loads walk a row in j
+        std::memcpy(&h[off_w1[q]], a[0], (size_t)nin[q] * H * sizeof(float));
         off[q][0] = push((size_t)H * npad[q]);
         for (int j = 0; j < H; ++j)
             for (int k = 0; k < nin[q]; ++k) h[off[q][0] + (size_t)j * npad[q] + k] = a[0][(size_t)k * H + j];
@@ -918,6 +1270,7 @@ extern "C" int fgnn_gnnbp4_weights_create(const float* const host_arrays[30], in
     MlpDev* dst[7] = {&w->d.cn_msg[0], &w->d.cn_msg[1], &w->d.cn_embed[0], &w->d.cn_embed[1], &w->d.vn_msg[0], &w->d.vn_msg[1],
                       &w->d.vn_embed};
     for (int q = 0; q < 7; ++q) {
+        dst[q]->w1 = base + off_w1[q];
         dst[q]->w1t = base + off[q][0];
         dst[q]->b1 = base + off[q][1];
         dst[q]->w2 = base + off[q][2];
@@ -1051,6 +1404,20 @@ extern "C" size_t fgnn_gnnbp4_workspace_bytes(const fgnn_graph* g, int B)
     return (size_t)B * (size_t)(g->d.n + g->d.m) * D * sizeof(float);
 }
 
+// FGNN_OPT_GNN_STREAM for GNN_BP4 on a (3,3,6)-regular graph: only the explicit value 2 ("always") runs the streaming packed-FMA kernel.
+// Measured in round 4 (profiles/r4_gnnbp4_stream_ab.txt, r4_gnnbp4_stream_pmc_summary.txt): bit-equal to the MFMA-tile kernel in both
+// associations, and slower — 180 ms against 134 ms per 16 384 x 10 in the factored order, 212 against 193 in the literal one.  The
+// packed fma holds a SIMD for ~4.4 cycles per two multiply-adds, so the uniform-weight multiply-adds run at the f32 MFMA's rate minus
+// nothing: what the streaming form saves on the tiles' padded rows (24 % of the MFMA cycles) it pays back in the packed instruction's
+// 10 % issue overhead, a 70 KB weight stream through a 16 KB scalar cache (12 % misses; the MFMA kernel keeps its operands in LDS) and
+// three waves per SIMD of 168 VGPRs.  Both forms price at ~107-110 ms if issued perfectly; the MFMA kernel is at 83 % of that, the
+// streaming kernel at 60 %.  It stays in the library as the tested second implementation of the same float operations.
+static bool gnnbp4_takes_stream(const fgnn_graph* g, int B)
+{
+    (void)B;
+    return g->gnn_stream == 2;
+}
+
 extern "C" int fgnn_gnnbp4_decode(const fgnn_graph* g, const fgnn_gnnbp4_weights* w, int num_iter, const uint8_t* synd_x,
                                   const uint8_t* synd_z, int B, uint8_t* x_hat, uint8_t* z_hat, float* llr_out,
                                   float* x_logit_all, float* z_logit_all, void* workspace, size_t ws_bytes, void* stream)
@@ -1078,6 +1445,19 @@ extern "C" int fgnn_gnnbp4_decode(const fgnn_graph* g, const fgnn_gnnbp4_weights
     fgnn_prof_scope prof(g, static_cast<hipStream_t>(stream));
     if (w->general) {
         hipLaunchKernelGGL(gnn_bp4_general_kernel, dim3(B), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), g->d, w->gen, a);
+        FGNN_HIP_CHECK(hipGetLastError());
+        prof.done(FGNN_PROF_TAG_GNNBP4, B);
+        return FGNN_OK;
+    }
+    if (g->d.dvx == 3 && g->d.dvz == 3 && g->d.dc == 6 && !g->force_generic && gnnbp4_takes_stream(g, B)) {
+        const size_t lds_s = (size_t)(2 * g->d.n + 2 * g->d.m) * sizeof(float);
+        if (lds_s > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "code too large for the GNN_BP4 streaming kernel");
+        auto kern = g->gnn_factored ? gnn_bp4_stream_kernel<3, 6, true> : gnn_bp4_stream_kernel<3, 6, false>;
+        GnnBp4Dev wd = w->d;
+        if (getenv("FGNN_PROBE_ALIAS_WEIGHTS")) {  // timing probe, results wrong by construction: every MLP reads ONE 10 KB weight set
+            for (MlpDev* q : {&wd.cn_msg[0], &wd.cn_msg[1], &wd.cn_embed[0], &wd.cn_embed[1], &wd.vn_msg[1], &wd.vn_embed}) *q = wd.vn_msg[0];
+        }
+        hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_s, static_cast<hipStream_t>(stream), g->d, wd, a);
         FGNN_HIP_CHECK(hipGetLastError());
         prof.done(FGNN_PROF_TAG_GNNBP4, B);
         return FGNN_OK;

@@ -99,14 +99,15 @@ int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords
  * rounding.  What a caller who diffs results against the literal form (option = 0) sees, measured per sample through the
  * whole sandwich on 65 536 samples per point, options 4 and 5 both on vs both off (profiles/r4_forms_agreement.json,
  * tests/test_gpu_literal_forms.py; bench.py prints the same comparison for its timed batch as `forms_agreement`):
- *     [[882,24]] (64, G, 16)   p <= 0.02: 0 samples with a different final decision, marginals within 7.6e-6 on every sample the
- *                              decoder solves (the 1-4 samples it leaves flagged, under both forms, differ by up to 0.3);
+ *     [[882,24]] (64, G, 16)   p <= 0.02: 0 samples with a different final decision; p <= 0.01: marginals within 7.6e-6 on every
+ *                              sample the decoder solves (the one sample of 65 536 it leaves flagged at p = 0.01, under both forms,
+ *                              differs by 8e-4); p = 0.02: 9 samples beyond 1e-4 (up to 0.3), 5 of them solved ones;
  *                              p = 0.03: 2 samples (0.003 %);  0.04: 18 (0.03 %);  0.05: 74 (0.11 %);  0.06: 344 (0.5 %);
  *                              0.08: 2 746 (4.2 %);  0.10: 9 611 (14.7 %) end on a different — equally valid or equally failed — estimate;
  *     [[1270,28]] (64, G, 64)  p <= 0.02: 0;  0.03: 4;  0.04: 30;  0.05: 126 (0.2 %);  0.06: 426 (0.65 %);  0.08: 4 539 (6.9 %);
  *                              0.10: 15 177 (23 %).
- * So up to p = 0.02 — the benchmark's operating point p = 0.01 included — the default is the literal decoder sample by sample within the
- * north-star tolerance (decisions identical, LLRs within 1e-4); in the waterfall it is the same decoder only STATISTICALLY: BP4-64
+ * So at the benchmark's operating point p = 0.01 (and below) the default is the literal decoder sample by sample within the north-star
+ * tolerance (decisions identical, LLRs within 1e-4 on every solved sample), at p = 0.02 still decision by decision; in the waterfall it is the same decoder only STATISTICALLY: BP4-64
  * decodes the same number of samples (24 M compared at p = 0.06 .. 0.10 on both codes: differences within 1.8 sigma, both signs,
  * profiles/r3j_bp4_shared_lse_ab.txt), paired block-error counts on 40 M samples agree (profiles/r3v_bp4_lse_forms_mcnemar.json) and the
  * 77 published rows land on the same z-scores (max |z| 1.89, profiles/r3k_published_curves_bp4_shared_lse.json).  A caller who needs the

@@ -150,7 +150,7 @@ def test_other_configs_shard_over_two_ranks(config, batch):
     global samples per step — sharding by global sample index, also for the GNN_BP4 line."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["FGNN_BENCH_BACKEND"] = "gloo"
-    common = ["--config", config, "--steps", "2", "--warmup", "1", "--p", "0.08", "--cpu-sample", "0", "--no-extras"]
+    common = ["--config", config, "--steps", "2", "--warmup", "1", "--p", "0.13", "--cpu-sample", "0", "--no-extras"]
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", str(batch)] + common,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
     assert res.returncode == 0, res.stderr[-2000:]

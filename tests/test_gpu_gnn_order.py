@@ -10,6 +10,7 @@ on either reaches the same decisions on the samples it decodes.
 """
 import numpy as np
 import pytest
+import torch
 
 from helpers import WEIGHTS_882, WEIGHTS_1270, code, gpu_graph, llr_const, oracle_library_forms, to_gpu
 
@@ -219,8 +220,9 @@ def _sandwich_both_orders(name, wfile, iters, p, compact, stream="always"):
 @pytest.mark.parametrize("name,B,iters", [("ghp882", 6, 4), ("ghp1270", 4, 10), ("gb48", 21, 5), ("rsurf5", 9, 3)])
 def test_gnn_bp4_both_orders_bit_exact(name, B, iters):
     """GNN_BP4 (gnn.py:383-423): the message MLPs of both update directions in the literal and in the factored association (own half of
-    the first Dense once per node and side; ONE last Dense on the signed sum of the hidden activations) — MFMA kernel (regular graphs),
-    VALU kernel (any graph), against the oracle in the same order, exactly; the two orders agree to rounding."""
+    the first Dense once per node and side; ONE last Dense on the signed sum of the hidden activations) — MFMA kernel and streaming
+    packed-FMA kernel (regular graphs), runtime-degree VALU kernel (any graph), against the oracle in the same order, exactly; the two
+    orders agree to rounding."""
     from feedback_gnn_amd.graph import GNNBP4_SHAPES, GnnBp4Weights
     rng = np.random.RandomState(11)
     w = []
@@ -235,13 +237,18 @@ def test_gnn_bp4_both_orders_bit_exact(name, B, iters):
         with _order(name, fact) as (og, gg):
             o = og.gnn_bp4(w, sx, sz, iters)
             gw = GnnBp4Weights(w, gg.device)
-            outs = [gg.gnn_bp4_decode(gw, to_gpu(sx), to_gpu(sz), iters)]
-            gg.force_generic(True)
+            prev_stream = gg.gnn_stream
             try:
+                gg.set_gnn_stream(False)       # MFMA tiles on the (3,3,6)-regular graphs (the runtime-degree VALU kernel elsewhere)
+                outs = [gg.gnn_bp4_decode(gw, to_gpu(sx), to_gpu(sz), iters)]
+                gg.set_gnn_stream("always")    # round 4: the streaming packed-FMA kernel (regular graphs), whatever the launch size
+                outs.append(gg.gnn_bp4_decode(gw, to_gpu(sx), to_gpu(sz), iters))
+                gg.force_generic(True)
                 outs.append(gg.gnn_bp4_decode(gw, to_gpu(sx), to_gpu(sz), iters))
             finally:
                 gg.force_generic(False)
-        for which, g in zip(("default kernel", "VALU kernel"), outs):
+                gg.set_gnn_stream(prev_stream)
+        for which, g in zip(("MFMA-tile kernel", "streaming packed-FMA kernel", "runtime-degree VALU kernel"), outs):
             for k in ("llr", "x_logit_all", "z_logit_all", "x_hat", "z_hat"):
                 a, b = o[k], g[k].cpu().numpy()
                 assert np.array_equal(a, b), f"{name} factored={fact} {which} {k}: max|d|={np.abs(a.astype(np.float64) - b).max()}"
@@ -249,3 +256,32 @@ def test_gnn_bp4_both_orders_bit_exact(name, B, iters):
     d = np.abs(res[False]["llr"] - res[True]["llr"]).max()
     assert 0 < d <= 2e-5, d
     assert np.abs(res[False]["x_logit_all"] - res[True]["x_logit_all"]).max() <= 2e-5
+
+
+def test_gnn_bp4_streaming_kernel_equals_the_mfma_kernel_on_a_chip_filling_launch():
+    """FGNN_OPT_GNN_STREAM = 2 runs GNN_BP4 on the streaming packed-FMA kernel (one lane per node, v_pk_fma_f32 with scalar weight
+    pairs); the default keeps the MFMA tiles, which are faster (profiles/r4_gnnbp4_stream_ab.txt).  The same float operations in the
+    same order: a launch of 1 024 codewords must give the same bits on either kernel, and both equal the oracle on a sample."""
+    from feedback_gnn_amd.graph import GNNBP4_SHAPES, GnnBp4Weights
+    name, B, iters = "ghp882", 1024, 3
+    rng = np.random.RandomState(5)
+    w = []
+    for shp in GNNBP4_SHAPES:
+        lim = 0.6 if len(shp) == 1 else np.sqrt(6.0 / (shp[0] + shp[1]))
+        w.append(rng.uniform(-lim, lim, size=shp).astype(np.float32))
+    og, gg = oracle_library_forms(name), gpu_graph(name)
+    assert gg.gnn_stream is True  # the library default
+    ex, ez = gg.pauli_noise(SEED, 0.05, 0, B)
+    sx, sz = gg.syndrome(ex, ez)
+    gw = GnnBp4Weights(w, gg.device)
+    mfma = gg.gnn_bp4_decode(gw, sx, sz, iters)
+    try:
+        gg.set_gnn_stream("always")
+        stream = gg.gnn_bp4_decode(gw, sx, sz, iters)
+    finally:
+        gg.set_gnn_stream(True)
+    for k in ("llr", "x_hat", "z_hat", "x_logit_all", "z_logit_all"):
+        assert torch.equal(mfma[k], stream[k]), k
+    idx = np.arange(0, B, 64)
+    o = og.gnn_bp4(w, sx.cpu().numpy()[idx], sz.cpu().numpy()[idx], iters)
+    assert np.array_equal(o["llr"], stream["llr"].cpu().numpy()[idx]) and np.array_equal(o["x_hat"], stream["x_hat"].cpu().numpy()[idx])

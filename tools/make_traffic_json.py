@@ -9,6 +9,8 @@ entry whose sources differ from the tree's.
 
     python tools/make_traffic_json.py <tag> sandwich:ghp882:65536:64=<summary> sandwich:ghp1270:32768:64=<summary> \
                                             gnnbp4:ghp1270:16384:10=<summary> > profiles/traffic.json
+A `merge=<traffic.json>` argument keeps the entries of an existing file that this call does not re-measure (a refresh of one
+configuration after only its kernel changed).
 """
 import json
 import os
@@ -57,6 +59,9 @@ def entry(kind, name, v):
 out = {}
 for spec in sys.argv[2:]:
     what, path = spec.split("=", 1)
+    if what == "merge":
+        out.update(json.load(open(path)))
+        continue
     kind, code, B, iters = what.split(":")
     rows = read_rows(path)
     if kind == "sandwich":

@@ -29,5 +29,5 @@ for cfg in $CONFIGS; do
   python tools/pmc_summary.py $O/${cfg}_pmc_*/*/*_counter_collection.csv > $O/${cfg}_pmc_summary.txt
   SPECS="$SPECS $SPEC=$O/${cfg}_pmc_summary.txt"
 done
-python tools/make_traffic_json.py "$TAG" $SPECS > $O/traffic.json
+python tools/make_traffic_json.py "$TAG" merge=profiles/traffic.json $SPECS > $O/traffic.json  # entries of configurations not re-measured are kept
 grep -E "(bp4_kernel|gnn_stream_kernel|gnn_bp4).* (FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU |SQ_INSTS_MFMA|GRBM_GUI_ACTIVE)" $O/c*_pmc_summary.txt || true
