@@ -34,7 +34,7 @@ def build(force=False, verbose=False):
 KERNEL_SOURCES = {
     "bp4": ("fgnn_bp4.hip", "fgnn_math.h", "fgnn_internal.h", "fgnn_rng.h", "Makefile"),
     "gnn": ("fgnn_gnn.hip", "fgnn_math.h", "fgnn_internal.h", "Makefile"),
-    "gnnbp4": ("fgnn_gnnbp4.hip", "fgnn_math.h", "fgnn_internal.h", "Makefile"),
+    "gnnbp4": ("fgnn_gnnbp4.hip", "fgnn_math.h", "fgnn_internal.h", "fgnn_pk.h", "Makefile"),
 }
 
 

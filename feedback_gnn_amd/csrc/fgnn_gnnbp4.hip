@@ -18,6 +18,7 @@
 
 #include "fgnn_internal.h"
 #include "fgnn_math.h"
+#include "fgnn_pk.h"
 
 namespace {
 
@@ -635,67 +636,10 @@ gnn_bp4_mfma_kernel(GraphDev g, GnnBp4Dev w, Args a, int tab_floats, int residen
 // so every output sees fmaf(in[k], W[k][j], acc) in ascending k from the oracle's start value — the oracle's bits — while consecutive
 // instructions are independent (no packed-math dependency stalls).  Hidden units are walked in five blocks of eight (four pairs): the
 // block's first-layer accumulators, its tanh values and the 20 second-layer accumulators they stream into are all that is live.
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef const f2 __attribute__((address_space(4)))* scalar_f2p;
-__device__ __forceinline__ scalar_f2p as_scalar2(const float* p) { return (scalar_f2p)(unsigned long long)p; }
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 bc2(float x) { return f2{x, x}; }
-
 constexpr int HB = 8, HBP = HB / 2, NHB = H / HB;  // hidden units per block, pairs per block, blocks
 constexpr int DP = D / 2;                          // an embedding / message vector as pairs of consecutive elements
 static_assert(H % HB == 0 && D % 4 == 0, "block / pair structure of the streaming GNN_BP4 kernel");
 
-// acc[jp] = fmaf(in[k], W[k][j0 + 2 jp + {0, 1}], acc[jp]) for k = 0 .. K-1 in this order; the K inputs arrive as (K + 1) / 2 pairs of
-// consecutive elements (element k = half k & 1 of pair k >> 1, picked by the instruction's op_sel: no broadcast copies); w = &W[0][j0],
-// row stride in floats.  The weight rows arrive through the scalar cache in groups of KG rows, one group ahead: scalar loads return
-// out of order, so the only wait there is is "all of them" (s_waitcnt lgkmcnt(0)); the group in use is therefore waited for FIRST (the
-// empty asm that names it), then the next group's loads are issued, then the group's packed fmas run — and the scheduler may not move
-// anything across the group boundaries (left alone it hoists every s_load of a layer to the top and spills hundreds of SGPRs).  The
-// input pairs pass through an empty asm at the top: a loop-invariant input would otherwise have its {x, x} broadcasts hoisted out of
-// the caller's block loop as twice as many live registers.
-template <int K, int JP, int KG>
-__device__ __forceinline__ void dense_pk(const f2 (&in2)[(K + 1) / 2], const float* w, int stride, f2 (&acc)[JP])
-{
-    constexpr int NG = (K + KG - 1) / KG, KP = (K + 1) / 2;
-    f2 x[KP];
-#pragma unroll
-    for (int q = 0; q < KP; ++q) {
-        x[q] = in2[q];
-        asm volatile("" : "+v"(x[q]));
-    }
-    f2 buf[2][KG][JP];
-#pragma unroll
-    for (int kk = 0; kk < KG; ++kk)
-        if (kk < K) {
-            scalar_f2p r = as_scalar2(w + kk * stride);
-#pragma unroll
-            for (int jp = 0; jp < JP; ++jp) buf[0][kk][jp] = r[jp];
-        }
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        asm volatile("" ::"s"(buf[g & 1][0][0]));  // the group's rows are in their SGPRs from here on
-        __builtin_amdgcn_sched_barrier(0);
-        if (g + 1 < NG) {
-#pragma unroll
-            for (int kk = 0; kk < KG; ++kk)
-                if ((g + 1) * KG + kk < K) {
-                    scalar_f2p r = as_scalar2(w + ((g + 1) * KG + kk) * stride);
-#pragma unroll
-                    for (int jp = 0; jp < JP; ++jp) buf[(g + 1) & 1][kk][jp] = r[jp];
-                }
-        }
-#pragma unroll
-        for (int kk = 0; kk < KG; ++kk)
-            if (g * KG + kk < K) {
-                const int k = g * KG + kk;
-                const f2 pr = x[k >> 1];
-                const f2 xb = (k & 1) ? __builtin_shufflevector(pr, pr, 1, 1) : __builtin_shufflevector(pr, pr, 0, 0);
-#pragma unroll
-                for (int jp = 0; jp < JP; ++jp) acc[jp] = pk_fma(xb, buf[g & 1][kk][jp], acc[jp]);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
 constexpr int KG1 = 4;  // first-layer rows (8 floats of a block) per group: 2 x 32 SGPRs in flight
 constexpr int KG2 = 1;  // last-layer rows (20 floats) per group: 2 x 20 SGPRs
 
@@ -715,7 +659,6 @@ __device__ __forceinline__ void store_row20(float* row, const f2 (&r)[DP])
 #pragma unroll
     for (int q = 0; q < D / 4; ++q) p[q] = make_float4(r[2 * q].x, r[2 * q].y, r[2 * q + 1].x, r[2 * q + 1].y);
 }
-__device__ __forceinline__ f2 tanh2(f2 a) { return f2{fg_tanh(a.x), fg_tanh(a.y)}; }
 
 // A whole two-layer MLP (oracle: mlp2) on a register vector of NIN elements: out = tanh(in W1 + b1) W2 + b2, hidden units in blocks of eight.
 template <int NIN>

@@ -1,33 +1,29 @@
 #!/bin/bash
 # One gpurun call that produces everything profiles/ cites for a round:  bash tools/final_profile.sh <tag>
-# (GPU tests, bench line, rocprofv3 kernel trace of the same bench command, PMC passes on the fixed-dataflow kernels)
+# (GPU tests; the PMC passes of all three BASELINE configurations -> traffic.json; the three bench lines; a rocprofv3 kernel trace of the
+# same bench commands; the batch-size table).  Copy what is to be judged from gpurun_out/<tag>/ into profiles/ afterwards.
 set -e
 TAG=${1:-r00}
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1 || { tail -30 $O/pytest_gpu.log; exit 1; }
 tail -2 $O/pytest_gpu.log
-python bench.py > $O/bench.json 2> $O/bench.err
-python bench.py --code ghp1270 --iters 64,64 --batch 32768 --cpu-sample 0 --no-extras --no-build > $O/bench_c4shape_ghp1270.json 2>> $O/bench.err || true
-cat $O/bench.json
-export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-extras --no-build > $O/trace_bench.json 2>&1
-for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_WAIT_INST_LDS"; do
-  tag=$(echo $set | cut -d' ' -f1)
-  timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $O/pmc_$tag -- python3 tools/prof_kernels.py ghp882 65536 fixed > $O/pmc_$tag.log 2>&1
+# counts first: the bench lines below then quote THIS library's PMC passes (library_is_the_profiled_binary: true)
+bash tools/refresh_traffic.sh $TAG c3 c4 c5 > $O/refresh.log 2>&1
+cp $O/traffic.json profiles/traffic.json
+python bench.py --no-build --require-roofline > $O/bench_c3.json 2> $O/bench.err
+python bench.py --no-build --config c4 --require-roofline > $O/bench_c4.json 2>> $O/bench.err
+python bench.py --no-build --config c5 --require-roofline > $O/bench_c5.json 2>> $O/bench.err
+cat $O/bench_c3.json
+# kernel traces of the same commands (no CPU legs, no extras: the launches of the timed region + the literal-forms region + forms_agreement)
+for cfg in c3 c4 c5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$cfg -- python3 bench.py --config $cfg --steps 3 --warmup 1 --cpu-sample 0 --no-extras --no-build > $O/trace_bench_$cfg.json 2>&1
+  python tools/dispatch_summary.py $O/trace_$cfg/*/*_kernel_trace.csv > $O/dispatches_$cfg.txt
+  cp $O/trace_$cfg/*/*_kernel_stats.csv $O/kernel_stats_$cfg.csv
 done
-python tools/pmc_summary.py $O/pmc_*/*/*_counter_collection.csv > $O/pmc_summary.txt
-# GNN_BP4 (BASELINE configs[4]) at its per-GPU shard shape, 16 384 codewords x 10 iterations: timing + the same counter passes
-python tools/bench_gnnbp4.py 16384 > $O/gnnbp4_c5shape.txt 2>&1 || true
-for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_WAIT_INST_LDS"; do
-  tag=$(echo $set | cut -d' ' -f1)
-  timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $O/c5pmc_$tag -- python3 tools/prof_gnnbp4.py 16384 > $O/c5pmc_$tag.log 2>&1
-done
-python tools/pmc_summary.py $O/c5pmc_*/*/*_counter_collection.csv > $O/c5_pmc_summary.txt
-cat $O/gnnbp4_c5shape.txt
-python tools/dispatch_summary.py $O/trace/*/*_kernel_trace.csv > $O/dispatches.txt
-cat $O/dispatches.txt
-python tools/make_traffic_json.py $O/pmc_summary.txt "$TAG" > $O/traffic.json
+cat $O/dispatches_c3.txt
+python tools/batch_size_table.py $O/batch_sizes.json > $O/batch_sizes.txt 2>&1 || true
 python tools/harness_rate.py 0.05 3 40 2>&1 | grep "^(" > $O/harness_rate.txt || true
-grep -E "bp4_kernel.* (FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU |GRBM_GUI_ACTIVE)" $O/pmc_summary.txt || true
+grep -E "(bp4_kernel|gnn_stream_kernel|gnn_bp4).* (FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU |SQ_INSTS_MFMA|GRBM_GUI_ACTIVE)" $O/c*_pmc_summary.txt || true
