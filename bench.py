@@ -799,8 +799,7 @@ def main():
         if cpu_check is not None:
             S, o, fl = cpu_check
             if is_c5:
-                state_first = 0
-                ex, ez = g.pauli_noise(SEED, args.p, state_first, S)
+                ex, ez = g.pauli_noise(SEED, args.p, 0, S)
                 sx, sz = g.syndrome(ex, ez)
                 d = g.gnn_bp4_decode(wdev, sx, sz, iters[0], return_logits=False)
                 d["noise_x"], d["noise_z"] = ex, ez
@@ -880,7 +879,12 @@ def main():
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
-        dist.destroy_process_group()
+        # rank 0 alone ran forms_agreement after the timed regions: the others wait for it here, so that no rank tears its
+        # communicator down while a peer is still inside the job
+        try:
+            dist.barrier()
+        finally:
+            dist.destroy_process_group()
     if rank == 0 and args.require_roofline and out["roofline"].get("frac") is None:
         sys.stderr.write(f"bench.py: --require-roofline: roofline.frac is null ({out['roofline'].get('traffic_source')})\n")
         sys.exit(5)
