@@ -112,6 +112,8 @@ _SIGNATURES = {
     "fgnn_bp4_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
                           + [C.c_void_p] * 7),
     "fgnn_feedback_gnn_backward": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 9),
+    "fgnn_feedback_gnn_backward_general": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3
+                                           + [C.c_int, C.c_void_p]),
 }
 
 ABI_SYMBOLS = tuple(_SIGNATURES)

@@ -16,6 +16,8 @@
 // constants (tf.stop_gradient, decoding_q.py:392-409).  With phi(x) = -log tanh(x/2): phi'(x) = -1/sinh(x).
 // Checked against autograd of the float64 restatement (oracle/torch_ref.py) in tests/test_gpu_backward.py; no bit-level
 // claim is made for gradients (float32 here, tolerance in the test).
+#include <cstring>
+
 #include "fgnn_internal.h"
 #include "fgnn_math.h"
 
@@ -369,6 +371,214 @@ __global__ void __launch_bounds__(256) gnn_backward_kernel(GraphDev g, WeightsDe
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Reverse pass of the RUNTIME-SHAPED feedback GNN (fgnn_weights_create_general: any num_msg_dims / num_hidden_units / num_mlp_layers /
+// reduce_op / activation / use_bias the reference's constructor accepts) — the reference trains whatever Feedback_GNN.__init__ built
+// (feedback_gnn.py:423-463 under tf.GradientTape).  Same division of labour as gnn_backward_kernel: one thread per qubit recomputes the
+// forward (the float operations of gnn_general_kernel) and leaves, for every Dense layer in execution order, its input activations
+// and the gradient at its pre-activation in HBM; the sums over batch x edges (weight gradient = activations^T deltas, bias gradient =
+// column sums of the deltas) are library GEMMs on the caller's side.  Reduce ops: sum / mean pass the gradient through (/ deg for
+// mean); max / min route it to the edges that attain the extremum, shared equally among ties (TensorFlow's _MinOrMaxGrad).
+// Activation derivatives are formed from the activation's output (tanh: 1 - h^2, sigmoid: h (1 - h), relu: h > 0, linear: 1).
+// The compatibility path: activations of a whole MLP live in per-thread scratch.
+struct GnnGenBwArgs {
+    int B;
+    const float* llr;
+    const float* logit_hx;
+    const float* logit_hz;
+    const uint8_t* synd_x;
+    const uint8_t* synd_z;
+    const float* gout;                      // [B,3,n]
+    float* acts[FGNN_GEN_MAX_LAYERS];       // layer li: [rows_li, K_li]; rows = B*E_x | B*E_z (message MLPs), B*n (embed MLP, _llr_inv_embed)
+    float* deltas[FGNN_GEN_MAX_LAYERS];     // layer li: [rows_li, J_li]
+};
+
+__device__ __forceinline__ float gen_act_bw(float a, int act)
+{
+    switch (act) {
+    case FGNN_ACT_TANH: return fg_tanh(a);
+    case FGNN_ACT_RELU: return FG_MAX(a, 0.0f);
+    case FGNN_ACT_SIGMOID: return fg_sigmoid(a);
+    default: return a;
+    }
+}
+__device__ __forceinline__ float gen_act_deriv(float h, int act)
+{
+    switch (act) {
+    case FGNN_ACT_TANH: return 1.0f - h * h;
+    case FGNN_ACT_RELU: return h > 0.0f ? 1.0f : 0.0f;
+    case FGNN_ACT_SIGMOID: return h * (1.0f - h);
+    default: return 1.0f;
+    }
+}
+__device__ __forceinline__ void gen_dense_bw(const GnnGeneralDev& w, int li, const float* in, float* out)
+{
+    const int K = w.K[li], J = w.J[li], act = w.act_l[li];
+    const float* W = w.W[li];
+    const float* b = w.b[li];
+    for (int j = 0; j < J; ++j) {
+        float a = 0.0f;
+        for (int k = 0; k < K; ++k) a = FG_FMA(in[k], W[k * J + j], a);
+        if (b) a = a + b[j];
+        out[j] = gen_act_bw(a, act);
+    }
+}
+// d in[k] = sum_j W[k][j] delta[j]
+__device__ __forceinline__ void gen_dense_back(const GnnGeneralDev& w, int li, const float* delta, float* din)
+{
+    const int K = w.K[li], J = w.J[li];
+    const float* W = w.W[li];
+    for (int k = 0; k < K; ++k) {
+        float a = 0.0f;
+        for (int j = 0; j < J; ++j) a = FG_FMA(W[k * J + j], delta[j], a);
+        din[k] = a;
+    }
+}
+
+constexpr int GBW_W = FGNN_GEN_MAX_W > 2 * FGNN_GEN_MAX_D + 3 ? FGNN_GEN_MAX_W : 2 * FGNN_GEN_MAX_D + 3;  // widest activation vector
+
+__global__ void __launch_bounds__(256) gnn_general_backward_kernel(GraphDev g, GnnGeneralDev w, GnnGenBwArgs a)
+{
+    extern __shared__ float lds[];
+    float* gcn = lds;  // [m_x] then [m_z]: h_cn of :168-172
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, n = g.n;
+    for (int c = tid; c < g.m_x; c += nt)
+        gcn[c] = a.logit_hx[(size_t)b * g.m_x + c] * ((a.synd_x[(size_t)b * g.m_x + c] & 1) ? -1.0f : 1.0f);
+    for (int c = tid; c < g.m_z; c += nt)
+        gcn[g.m_x + c] = a.logit_hz[(size_t)b * g.m_z + c] * ((a.synd_z[(size_t)b * g.m_z + c] & 1) ? -1.0f : 1.0f);
+    __syncthreads();
+    const int D = w.D, L = w.L, rop = w.reduce_op;
+    const bool extremum = rop == FGNN_REDUCE_MAX || rop == FGNN_REDUCE_MIN;
+    const float* in = a.llr + (size_t)b * 3 * n;
+    const float* go = a.gout + (size_t)b * 3 * n;
+    float ha[5][GBW_W];                 // activations of the MLP at hand: ha[0] = its input, ha[l + 1] = output of its layer l
+    float z[2 * FGNN_GEN_MAX_D + 3];    // [reduced_x | reduced_z | X Y Z]
+    float cnt[2][FGNN_GEN_MAX_D];       // max / min: how many edges attain the extremum, per component
+    float dz[GBW_W], dA[GBW_W], dB[GBW_W];
+    for (int v = tid; v < n; v += nt) {
+        const float X = in[v], Y = in[n + v], Z = in[2 * n + v];
+        // ---- forward of the message MLPs and the reduce (gnn_general_kernel's operations) ----
+        for (int s = 0; s < 2; ++s) {
+            const int* vptr = s == 0 ? g.vptr_x : g.vptr_z;
+            const float* gc = s == 0 ? gcn : gcn + g.m_x;
+            const int e0 = vptr[v], e1 = vptr[v + 1];
+            float* acc = z + s * D;
+            for (int i = 0; i < D; ++i) acc[i] = 0.0f;
+            for (int e = e0; e < e1; ++e) {
+                ha[0][0] = gc[g.vchk[e]];
+                ha[0][1] = X;
+                ha[0][2] = Y;
+                ha[0][3] = Z;
+                for (int l = 0; l < L; ++l) gen_dense_bw(w, s * L + l, ha[l], ha[l + 1]);
+                for (int i = 0; i < D; ++i) {
+                    const float m = ha[L][i];
+                    float r;
+                    if (e == e0) r = m;
+                    else if (rop == FGNN_REDUCE_MAX) r = FG_MAX(acc[i], m);
+                    else if (rop == FGNN_REDUCE_MIN) r = FG_MIN(acc[i], m);
+                    else r = acc[i] + m;
+                    acc[i] = r;
+                }
+            }
+            if (rop == FGNN_REDUCE_MEAN && e1 > e0) {
+                const float fd = (float)(e1 - e0);
+                for (int i = 0; i < D; ++i) acc[i] = acc[i] / fd;
+            }
+            if (extremum) {  // ties share the gradient: count the edges that attain the extremum
+                for (int i = 0; i < D; ++i) cnt[s][i] = 0.0f;
+                for (int e = e0; e < e1; ++e) {
+                    ha[0][0] = gc[g.vchk[e]];
+                    ha[0][1] = X;
+                    ha[0][2] = Y;
+                    ha[0][3] = Z;
+                    for (int l = 0; l < L; ++l) gen_dense_bw(w, s * L + l, ha[l], ha[l + 1]);
+                    for (int i = 0; i < D; ++i) cnt[s][i] += (ha[L][i] == acc[i]) ? 1.0f : 0.0f;
+                }
+            }
+        }
+        z[2 * D] = X;
+        z[2 * D + 1] = Y;
+        z[2 * D + 2] = Z;
+        // ---- embed MLP + _llr_inv_embed: forward with every activation kept, then backward ----
+        const size_t nrow = (size_t)b * n + v;
+        for (int k = 0; k < 2 * D + 3; ++k) ha[0][k] = z[k];
+        for (int l = 0; l < L - 1; ++l) gen_dense_bw(w, 2 * L + l, ha[l], ha[l + 1]);
+        for (int l = 0; l < L; ++l) {  // inputs of the L - 1 embed layers and of _llr_inv_embed (layer 3L - 1, input ha[L - 1])
+            const int li = l < L - 1 ? 2 * L + l : 3 * L - 1, K = w.K[li];
+            float* o = a.acts[li] + nrow * K;
+            for (int k = 0; k < K; ++k) o[k] = ha[l][k];
+        }
+        {
+            const int li = 3 * L - 1;
+            float* d = a.deltas[li] + nrow * 3;
+            dA[0] = go[v];
+            dA[1] = go[n + v];
+            dA[2] = go[2 * n + v];
+            d[0] = dA[0];
+            d[1] = dA[1];
+            d[2] = dA[2];
+            gen_dense_back(w, li, dA, dB);  // d ha[L - 1]
+        }
+        float* dcur = dB;
+        float* dnxt = dA;
+        for (int l = L - 2; l >= 0; --l) {
+            const int li = 2 * L + l, J = w.J[li];
+            float* d = a.deltas[li] + nrow * J;
+            for (int j = 0; j < J; ++j) {
+                dnxt[j] = dcur[j] * gen_act_deriv(ha[l + 1][j], w.act_l[li]);
+                d[j] = dnxt[j];
+            }
+            gen_dense_back(w, li, dnxt, dcur);  // d ha[l] (dcur is free again: its values went into dnxt)
+        }
+        for (int k = 0; k < 2 * D; ++k) dz[k] = dcur[k];
+        // ---- message MLPs backward (activations recomputed per edge) ----
+        for (int s = 0; s < 2; ++s) {
+            const int* vptr = s == 0 ? g.vptr_x : g.vptr_z;
+            const float* gc = s == 0 ? gcn : gcn + g.m_x;
+            const int e0 = vptr[v], e1 = vptr[v + 1], Es = s == 0 ? g.E_x : g.E_z, ebase = s == 0 ? 0 : g.E_x;
+            const float fd = (float)(e1 - e0);
+            for (int e = e0; e < e1; ++e) {
+                const size_t row = (size_t)b * Es + (e - ebase);
+                ha[0][0] = gc[g.vchk[e]];
+                ha[0][1] = X;
+                ha[0][2] = Y;
+                ha[0][3] = Z;
+                for (int l = 0; l < L; ++l) gen_dense_bw(w, s * L + l, ha[l], ha[l + 1]);
+                for (int l = 0; l < L; ++l) {
+                    const int li = s * L + l, K = w.K[li];
+                    float* o = a.acts[li] + row * K;
+                    for (int k = 0; k < K; ++k) o[k] = ha[l][k];
+                }
+                // gradient at the message (output of the last, linear layer) through the reduce
+                for (int i = 0; i < D; ++i) {
+                    const float gr = dz[s * D + i];
+                    float dm;
+                    if (rop == FGNN_REDUCE_MEAN) dm = gr / fd;
+                    else if (extremum) dm = (ha[L][i] == z[s * D + i]) ? gr / cnt[s][i] : 0.0f;
+                    else dm = gr;
+                    dA[i] = dm;
+                }
+                float* dc = dA;
+                float* dn = dB;
+                for (int l = L - 1; l >= 0; --l) {
+                    const int li = s * L + l, J = w.J[li];
+                    float* d = a.deltas[li] + row * J;
+                    if (l < L - 1)
+                        for (int j = 0; j < J; ++j) dc[j] = dc[j] * gen_act_deriv(ha[l + 1][j], w.act_l[li]);
+                    for (int j = 0; j < J; ++j) d[j] = dc[j];
+                    if (l > 0) {
+                        gen_dense_back(w, li, dc, dn);
+                        float* t = dc;
+                        dc = dn;
+                        dn = t;
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int fgnn_bp4_backward(const fgnn_graph* g, int num_iter, float normalization_factor, const float* llr_ch,
@@ -455,6 +665,45 @@ extern "C" int fgnn_feedback_gnn_backward(const fgnn_graph* g, const fgnn_weight
         FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), g->d, w->d, a);
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_feedback_gnn_backward_general(const fgnn_graph* g, const fgnn_weights* w, const float* llr, const float* logit_hx,
+                                                  const float* logit_hz, const uint8_t* synd_x, const uint8_t* synd_z, int B,
+                                                  const float* grad_out, float* const* acts, float* const* deltas, int num_layers,
+                                                  void* stream)
+{
+    if (!g || !w) return fgnn_fail(FGNN_ERR_ARG, "graph or weights is NULL");
+    if (!w->general) return fgnn_fail(FGNN_ERR_ARG, "fgnn_feedback_gnn_backward_general takes weights made by fgnn_weights_create_general");
+    if (!llr || !logit_hx || !logit_hz || !synd_x || !synd_z || !grad_out || !acts || !deltas) return fgnn_fail(FGNN_ERR_ARG, "buffer is NULL");
+    if (num_layers != w->gen.nl) return fgnn_fail(FGNN_ERR_ARG, "num_layers must be 3 * num_mlp_layers (one activation / delta pair per Dense layer)");
+    for (int li = 0; li < num_layers; ++li)
+        if (!acts[li] || !deltas[li]) return fgnn_fail(FGNN_ERR_ARG, "buffer is NULL");
+    if (B < 0) return fgnn_fail(FGNN_ERR_ARG, "B must be >= 0");
+    if (w->device != g->device) return fgnn_fail(FGNN_ERR_ARG, "weights and graph live on different devices");
+    if (B == 0) return FGNN_OK;
+    FGNN_DEVICE_GUARD(g->device);
+    GnnGenBwArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.B = B;
+    a.llr = llr;
+    a.logit_hx = logit_hx;
+    a.logit_hz = logit_hz;
+    a.synd_x = synd_x;
+    a.synd_z = synd_z;
+    a.gout = grad_out;
+    for (int li = 0; li < num_layers; ++li) {
+        a.acts[li] = acts[li];
+        a.deltas[li] = deltas[li];
+    }
+    const size_t lds_bytes = (size_t)g->d.m * sizeof(float);
+    if (lds_bytes > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "too many checks for the LDS-resident kernel");
+    auto kern = gnn_general_backward_kernel;
+    if (lds_bytes > 48 * 1024)
+        FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), g->d, w->gen, a);
     FGNN_HIP_CHECK(hipGetLastError());
     return FGNN_OK;
 }

@@ -62,7 +62,8 @@ class Feedback_GNN:
 
     @property
     def is_shipped_architecture(self):
-        """True for num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, mean, tanh, bias: the MFMA kernel and the reverse pass."""
+        """True for num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, mean, tanh, bias: the streaming / MFMA kernels and their
+        specialised reverse pass; every other setting runs the runtime-shaped kernels, forward and (round 4) reverse."""
         return self._config == SHIPPED_GNN_CONFIG
 
     def get_weights(self):
@@ -343,9 +344,6 @@ class Second_Stage_GNN_BP_Model:
     def value_and_grad(self, noise_x, noise_z, h_vn, logit_hx_perp, logit_hz_perp):
         """``(s_hat, ls_hat, loss, grads)``: what ``with tf.GradientTape() as tape: ... = model(...)`` followed by
         ``tape.gradient(loss, model.trainable_variables)`` yields in Feedback_GNN.ipynb cell 8."""
-        if not self.feedback.is_shipped_architecture:
-            raise NotImplementedError("the reverse pass exists for num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, "
-                                      "reduce_op='mean', activation='tanh', use_bias=True only")
         g, ex, ez, sx, sz = self._inputs(noise_x, noise_z, h_vn, logit_hx_perp, logit_hz_perp)
         dev = g.device
         llr_in = torch.as_tensor(h_vn, device=dev, dtype=torch.float32).permute(0, 2, 1).contiguous()

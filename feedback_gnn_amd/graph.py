@@ -354,6 +354,28 @@ class TannerGraph:
         synd_x = self._chk(synd_x, (B, self.m_x), torch.uint8, "synd_x")
         synd_z = self._chk(synd_z, (B, self.m_z), torch.uint8, "synd_z")
         grad_out = self._chk(grad_out, (B, 3, self.n), torch.float32, "grad_out")
+        if weights.general:
+            # any constructor setting (fgnn_feedback_gnn_backward_general): one (input activations, pre-activation delta) pair per Dense
+            # layer in execution order; the gradients come back in the order of get_weights() (_llr_inv_embed first)
+            D, H, L, _, _, bias = weights.config
+            shapes = [(4 if l == 0 else H, D if l == L - 1 else H) for _ in range(2) for l in range(L)]
+            shapes += [(2 * D + 3 if l == 0 else H, H) for l in range(L - 1)]
+            shapes += [(H if L > 1 else 2 * D + 3, 3)]
+            rows = [B * self.E_x] * L + [B * self.E_z] * L + [B * self.n] * L
+            acts = [self._new((r, k), torch.float32) for r, (k, _) in zip(rows, shapes)]
+            deltas = [self._new((r, j), torch.float32) for r, (_, j) in zip(rows, shapes)]
+            pa = (C.c_void_p * len(acts))(*[t.data_ptr() for t in acts])
+            pd = (C.c_void_p * len(deltas))(*[t.data_ptr() for t in deltas])
+            check(_lib.lib().fgnn_feedback_gnn_backward_general(self.handle, weights.handle, _ptr(llr), _ptr(logit_hx), _ptr(logit_hz),
+                                                                _ptr(synd_x), _ptr(synd_z), B, _ptr(grad_out), pa, pd, len(acts),
+                                                                _stream(self.device)))
+            grads = []
+            for f in range(3 * L):
+                li = 3 * L - 1 if f == 0 else f - 1
+                grads.append(acts[li].t() @ deltas[li])
+                if bias:
+                    grads.append(deltas[li].sum(0))
+            return grads
         node_in = self._new((B * self.n, 44), torch.float32)
         node_h2 = self._new((B * self.n, 40), torch.float32)
         node_d2 = self._new((B * self.n, 40), torch.float32)

@@ -327,6 +327,15 @@ int fgnn_feedback_gnn_backward(const fgnn_graph* g, const fgnn_weights* w, const
                                const float* grad_out, float* node_in, float* node_h2, float* node_d2,
                                float* const edge_feat[2], float* const edge_h1[2], float* const edge_d1[2],
                                float* const edge_dm[2], void* stream);
+/* The same for weights made by fgnn_weights_create_general (any constructor setting of Feedback_GNN: the reference trains whatever
+ * feedback_gnn.py:21-128 built, :423-463).  For Dense layer li in EXECUTION order — [0, L) vn_msg_mlp_x, [L, 2L) vn_msg_mlp_z,
+ * [2L, 3L-1) vn_embed_mlp, 3L-1 _llr_inv_embed; L = num_mlp_layers, num_layers = 3L — the kernel leaves acts[li] [rows, K_li] = the
+ * layer's input and deltas[li] [rows, J_li] = d loss / d (its pre-activation), rows = B*E_x / B*E_z (message MLPs, canonical edge
+ * order) or B*n; the caller forms W_li grad = acts^T deltas and b_li grad = column sums.  max / min reduce: the gradient goes to the
+ * edges attaining the extremum, shared equally among ties. */
+int fgnn_feedback_gnn_backward_general(const fgnn_graph* g, const fgnn_weights* w, const float* llr, const float* logit_hx,
+                                       const float* logit_hz, const uint8_t* synd_x, const uint8_t* synd_z, int B,
+                                       const float* grad_out, float* const* acts, float* const* deltas, int num_layers, void* stream);
 
 #ifdef __cplusplus
 }

@@ -107,6 +107,91 @@ def test_feedback_gnn_backward_matches_float64_autograd(name):
         assert _rel(got.cpu().numpy(), ref.grad.numpy()) < 1e-3, (i, _rel(got.cpu().numpy(), ref.grad.numpy()))
 
 
+@pytest.mark.parametrize("name,cfg", [("gb48", (8, 16, 1, "mean", "tanh", True)), ("rsurf5", (12, 24, 3, "sum", "relu", False)),
+                                      ("gb48", (20, 40, 2, "max", "sigmoid", True)), ("rsurf5", (6, 10, 4, "min", "tanh", True)),
+                                      ("ghp882", (16, 32, 2, "mean", "tanh", False)), ("gb48", (20, 40, 2, "mean", "tanh", True))])
+def test_general_feedback_gnn_backward_matches_float64_autograd(name, cfg):
+    """Round 4: the reverse pass for ANY constructor setting of Feedback_GNN (fgnn_feedback_gnn_backward_general) — widths, depth 1..4,
+    sum / mean / max / min (the gradient of an extremum goes to the edges that attain it), tanh / relu / sigmoid, with and without
+    bias, regular and irregular graphs — against autograd of the float64 restatement oracle/torch_ref.feedback_gnn_general.  The last
+    case is the shipped architecture forced onto the runtime-shaped path: it must also agree with the specialised reverse pass."""
+    from oracle import torch_ref as R
+    from feedback_gnn_amd.graph import ACTIVATIONS, REDUCE_OPS, GnnWeights, gnn_weight_shapes
+    D, H, L, red, act, bias = cfg
+    B = 3
+    g, sx, sz, llr = _case(name, B, 0.04, -2.0, 6.0)
+    rng = np.random.RandomState(17)
+    w = [rng.uniform(-0.5, 0.5, size=shp).astype(np.float32) for shp in gnn_weight_shapes(D, H, L, bias)]
+    lhx = rng.uniform(-4, 4, size=(B, g.m_x)).astype(np.float32)
+    lhz = rng.uniform(-4, 4, size=(B, g.m_z)).astype(np.float32)
+    gout = rng.normal(size=(B, 3, g.n)).astype(np.float32)
+    W = GnnWeights(w, g.device, config=cfg, force_general=True)
+    assert W.general
+    args = (to_gpu(llr), to_gpu(lhx), to_gpu(lhz), sx, sz)
+    fwd = g.feedback_gnn(W, *args)
+    grads = g.feedback_gnn_backward(W, *args, to_gpu(gout))
+
+    tg = R.Graph(code(name))
+    tw = [torch.from_numpy(a).to(R.DT).requires_grad_(True) for a in w]
+    out = R.feedback_gnn_general(tg, (D, H, L, REDUCE_OPS[red], ACTIVATIONS[act], bias), tw, torch.from_numpy(llr).to(R.DT),
+                                 torch.from_numpy(lhx).to(R.DT), torch.from_numpy(lhz).to(R.DT), sx.cpu(), sz.cpu())
+    scale = max(1.0, float(out.detach().abs().max()))
+    assert np.abs(fwd.cpu().numpy() - out.detach().numpy()).max() < 2e-4 * scale
+    (out * torch.from_numpy(gout).to(R.DT)).sum().backward()
+    assert len(grads) == len(tw) == 3 * L * (2 if bias else 1)
+    for i, (got, ref) in enumerate(zip(grads, tw)):
+        assert tuple(got.shape) == tuple(ref.shape), i
+        assert _rel(got.cpu().numpy(), ref.grad.numpy()) < 2e-3, (cfg, i, _rel(got.cpu().numpy(), ref.grad.numpy()))
+    if cfg == (20, 40, 2, "mean", "tanh", True):
+        special = g.feedback_gnn_backward(GnnWeights(w, g.device), *args, to_gpu(gout))
+        for i, (a, b) in enumerate(zip(grads, special)):
+            assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-4, i
+
+
+def test_value_and_grad_of_a_non_shipped_architecture_matches_float64_autograd():
+    """The training objective through the model classes with a Feedback_GNN the reference's constructor accepts but its weight files do
+    not use (12 message dims, 24 hidden units, 3 layers, sum, tanh, no bias): value_and_grad used to raise NotImplementedError for it.
+    Loss and all weight gradients against autograd of the float64 restatement (feedback_gnn_general -> bp4_logit_trace -> BCE)."""
+    from oracle import torch_ref as R
+    from feedback_gnn_amd import QLDPCBPDecoder, Feedback_GNN, First_Stage_BP_Model, Second_Stage_GNN_BP_Model
+    from feedback_gnn_amd.graph import ACTIVATIONS, REDUCE_OPS
+    name, B = "gb48", 6
+    c = code(name)
+    g = gpu_graph(name)
+    dec1 = QLDPCBPDecoder(code=c, num_iter=8, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True, graph=g)
+    dec2 = QLDPCBPDecoder(code=c, num_iter=6, normalization_factor=0.9, cn_type="boxplus-phi", stage_two=True, graph=g)
+    cfg = (12, 24, 3, "sum", "tanh", False)
+    G = Feedback_GNN(code=c, num_msg_dims=cfg[0], num_hidden_units=cfg[1], num_mlp_layers=cfg[2], reduce_op=cfg[3], activation=cfg[4],
+                     use_bias=cfg[5], graph=g)
+    assert not G.is_shipped_architecture
+    rng = np.random.RandomState(2)
+    w = [rng.uniform(-0.3, 0.3, size=a.shape).astype(np.float32) for a in G.get_weights()]
+    G.set_weights(w)
+    ex, ez = g.pauli_noise(SEED, 0.04, 0, B)
+    h_vn, lx, lz = First_Stage_BP_Model(c, dec1)(ex, ez)
+    m2 = Second_Stage_GNN_BP_Model(c, G, dec2, num_iter=6, loss_from=2)
+    s_hat, b_hat, loss, grads = m2.value_and_grad(ex, ez, h_vn, lx, lz)
+    s2, b2, loss2 = m2(ex, ez, h_vn, lx, lz)
+    assert torch.equal(s_hat, s2) and torch.equal(b_hat, b2) and abs(float(loss) - float(loss2)) < 1e-5 * max(1.0, abs(float(loss2)))
+
+    sx, sz = g.syndrome(ex, ez)
+    tg = R.Graph(c)
+    tw = [torch.from_numpy(a).to(R.DT).requires_grad_(True) for a in w]
+    tcfg = (cfg[0], cfg[1], cfg[2], REDUCE_OPS[cfg[3]], ACTIVATIONS[cfg[4]], cfg[5])
+    new_llr = R.feedback_gnn_general(tg, tcfg, tw, h_vn.permute(0, 2, 1).cpu().to(R.DT), lz.t().cpu().to(R.DT), lx.t().cpu().to(R.DT),
+                                     sx.cpu(), sz.cpu())  # the swap of feedback_gnn.py:436
+    xs, zs, _ = R.bp4_logit_trace(tg, new_llr, sx.cpu(), sz.cpu(), 6, 0.9)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    gt_x, gt_z = (1 - sz.cpu()).to(R.DT), (1 - sx.cpu()).to(R.DT)
+    ref = sum(bce(xs[i + 1], gt_x) + bce(zs[i + 1], gt_z) for i in range(2, 6))
+    ref.backward()
+    assert abs(float(loss) - ref.item()) < 1e-4 * max(1.0, abs(ref.item()))
+    assert len(grads) == len(tw)
+    for i, (got, t) in enumerate(zip(grads, tw)):
+        assert tuple(got.shape) == tuple(t.shape)
+        assert _rel(got.cpu().numpy(), t.grad.numpy()) < 5e-3, (i, _rel(got.cpu().numpy(), t.grad.numpy()))
+
+
 def test_second_stage_value_and_grad_matches_float64_autograd():
     """The whole training objective (GNN -> 16 stage_two iterations -> summed BCE, feedback_gnn.py:434-442) through the
     model class: loss and the 12 weight gradients vs oracle/torch_ref.second_stage_loss."""
@@ -205,8 +290,10 @@ def test_adam_step_follows_keras_update_rule():
     assert torch.allclose(v.cpu().double(), ref, atol=1e-6)
 
 
-def test_training_reduces_the_loss_on_a_fixed_set():
-    """A short run of the Feedback_GNN.ipynb loop on harvested BP failures of gb126: the objective goes down."""
+@pytest.mark.parametrize("arch", [(20, 40, 2, "mean", "tanh", True), (16, 32, 3, "sum", "tanh", True)])
+def test_training_reduces_the_loss_on_a_fixed_set(arch):
+    """A short run of the Feedback_GNN.ipynb loop on harvested BP failures of gb126: the objective goes down — with the architecture of
+    the shipped weights and (round 4) with another one the constructor accepts, trained through the runtime-shaped reverse pass."""
     from feedback_gnn_amd import (QLDPCBPDecoder, Feedback_GNN, Sandwich_BP_GNN_Evaluation_Model, First_Stage_BP_Model,
                                   Second_Stage_GNN_BP_Model)
     from feedback_gnn_amd.training import harvest_failures, train_second_stage
@@ -214,8 +301,8 @@ def test_training_reduces_the_loss_on_a_fixed_set():
     g = gpu_graph("gb126")
     dec1 = QLDPCBPDecoder(code=c, num_iter=32, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True, graph=g)
     dec2 = QLDPCBPDecoder(code=c, num_iter=16, normalization_factor=1.0, cn_type="boxplus-phi", stage_two=True, graph=g)
-    G = Feedback_GNN(code=c, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean", activation="tanh",
-                     use_bias=True, graph=g)
+    G = Feedback_GNN(code=c, num_msg_dims=arch[0], num_hidden_units=arch[1], num_mlp_layers=arch[2], reduce_op=arch[3],
+                     activation=arch[4], use_bias=arch[5], graph=g)
     ev = Sandwich_BP_GNN_Evaluation_Model(c, [dec1], [], num_layers=1)
     X, Z = harvest_failures(ev, 4096, 0.08, 400)
     assert X.shape[0] == 400
