@@ -106,8 +106,12 @@ int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords
  *                              0.08: 2 746 (4.2 %);  0.10: 9 611 (14.7 %) end on a different — equally valid or equally failed — estimate;
  *     [[1270,28]] (64, G, 64)  p <= 0.02: 0;  0.03: 4;  0.04: 30;  0.05: 126 (0.2 %);  0.06: 426 (0.65 %);  0.08: 4 539 (6.9 %);
  *                              0.10: 15 177 (23 %).
- * So at the benchmark's operating point p = 0.01 (and below) the default is the literal decoder sample by sample within the north-star
- * tolerance (decisions identical, LLRs within 1e-4 on every solved sample), at p = 0.02 still decision by decision; in the waterfall it is the same decoder only STATISTICALLY: BP4-64
+ * At scale (8 388 608 samples per point, profiles/r4_forms_agreement_8M.json): p = 0.01: 3 ([[882,24]]) / 6 ([[1270,28]]) samples with
+ * a different final decision (4e-7 / 7e-7 of the samples: the rare ones BP-64 takes long on), 40 / 4 solved samples beyond 1e-4;
+ * p = 0.02: 40 / 76 (5e-6 / 9e-6).
+ * So at the benchmark's operating point p = 0.01 the default is the literal decoder sample by sample within the north-star tolerance
+ * (decisions identical, LLRs within 1e-4) on all but a few samples in ten million — none in a batch of 65 536 —, at p = 0.02 on all but
+ * ~1e-5 of them; in the waterfall it is the same decoder only STATISTICALLY: BP4-64
  * decodes the same number of samples (24 M compared at p = 0.06 .. 0.10 on both codes: differences within 1.8 sigma, both signs,
  * profiles/r3j_bp4_shared_lse_ab.txt), paired block-error counts on 40 M samples agree (profiles/r3v_bp4_lse_forms_mcnemar.json) and the
  * 77 published rows land on the same z-scores (max |z| 1.89, profiles/r3k_published_curves_bp4_shared_lse.json).  A caller who needs the

@@ -1,7 +1,7 @@
 """Per-sample agreement of the library's default operation sequence with the reference's formulas term by term
 (FGNN_OPT_BP4_SHARED_LSE = FGNN_OPT_GNN_FACTORED = 0), through the whole (64, G, 16) / (64, G, 64) sandwich of the benchmark:
 
-    python tools/forms_agreement.py [samples_per_point] [out.json]
+    python tools/forms_agreement.py [samples_per_point] [out.json] [p,p,...]
 
 For every physical error rate: number of samples whose final decisions differ, max |dLLR| of the last decoder's marginals, number of
 samples with |dLLR| > 1e-4, samples left flagged by either form.  Same Philox samples for both forms."""
@@ -17,6 +17,7 @@ from feedback_gnn_amd.weights_io import read_weight_list  # noqa: E402
 
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 65536
 OUT = sys.argv[2] if len(sys.argv) > 2 else None
+PS = [float(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else (0.005, 0.01, 0.02, 0.03, 0.04, 0.05, 0.06, 0.08, 0.10)
 L0 = llr_const(0.05)
 rows = []
 
@@ -33,7 +34,7 @@ for name, wfile, iters in (("ghp882", WEIGHTS_882, [64, 16]), ("ghp1270", WEIGHT
     g = TannerGraph(code(name))
     g.set_saturation_shortcut(False)  # the benchmark's fixed dataflow (the shortcut is bit-identical anyway)
     w = GnnWeights(read_weight_list(wfile), g.device)
-    for p in (0.005, 0.01, 0.02, 0.03, 0.04, 0.05, 0.06, 0.08, 0.10):
+    for p in PS:
         tot = None
         for first in range(0, N, 65536):
             nb = min(65536, N - first)
