@@ -639,6 +639,7 @@ def main():
                              "traffic": traffic, "traffic_source": tsrc,
                              "mfma_insts_per_launch": mi, "valu_wave_insts_per_launch": vi,
                              "fp32_lane_busy_frac": lanes,
+                             "mfma_pipe_busy_frac": mi * 32 / (1024 * 2.4e9 * dom_ms * 1e-3) if (ent and dom_ms and mi is not None) else None,
                              "library_is_the_profiled_binary": ent.get("library_is_the_profiled_binary") if ent else None,
                              "avg_launch_ms": dom_ms, "launches_timed": len(dom),
                              "hbm_frac": traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if (traffic and dom_ms) else None,
