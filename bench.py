@@ -416,6 +416,230 @@ def cpu_legs_c5(args, code, weights, num_iter, seed, factored):
     return out, check
 
 
+def gnnbp4_roofline(code_name, dims, launches, B, num_iter, factored):
+    """`roofline` of the c5 line: the GNN_BP4 launch in the reference's FLOPs against the f32 MFMA (= f32 vector) peak, with the offline PMC
+    counts of this kernel at this shape (which pipe the time went to) while the kernel sources still hash to what was profiled."""
+    import numpy as np
+    n, m, E = dims
+    dom = [ms for ms, it, b in launches if it == PROF_TAG_GNNBP4 and b == B]
+    dom_ms = float(np.mean(dom)) if dom else None
+    flops = gnnbp4_flops_per_codeword(n, m, E, num_iter) * B
+    tf = flops / (dom_ms * 1e-3) / 1e12 if dom_ms else None
+    ent, tsrc = pmc_entry("gnnbp4", f"gnnbp4_{code_name}_it{num_iter}_B{B}")
+    if ent and not factored:
+        ent, tsrc = None, "profiles/traffic.json holds the counts of the default (factored) association; this run times the literal one"
+    traffic = ent.get("hbm_bytes_per_launch") if ent else None
+    vi = ent.get("valu_wave_insts_per_launch") if ent else None
+    mi = ent.get("mfma_insts_per_launch") if ent else None
+    simd_cycles = 1024 * 2.4e9 * dom_ms * 1e-3 if dom_ms else None
+    return {"bound": "valu" if (ent and not mi) else "mfma",
+            "kernel": f"GNN_BP4 kernel, {num_iter} iterations, B={B}",
+            "achieved": tf, "peak": GNN_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": (tf / GNN_PEAK_TFLOPS if tf else None) if ent else None,
+            "reference_tflops": tf, "reference_tflops_frac_of_f32_peak": tf / GNN_PEAK_TFLOPS if tf else None,
+            "algorithmic_flops_per_launch": flops,
+            "executed_flops_per_launch": gnnbp4_flops_per_codeword_factored(n, m, E, num_iter) * B if factored else None,
+            "traffic": traffic, "traffic_source": tsrc,
+            "mfma_insts_per_launch": mi, "valu_wave_insts_per_launch": vi,
+            "fp32_lane_busy_frac": (mi * 32 + vi * 2) / simd_cycles if (simd_cycles and mi is not None and vi is not None) else None,
+            "mfma_pipe_busy_frac": mi * 32 / simd_cycles if (simd_cycles and mi is not None) else None,
+            "library_is_the_profiled_binary": ent.get("library_is_the_profiled_binary") if ent else None,
+            "avg_launch_ms": dom_ms, "launches_timed": len(dom),
+            "hbm_frac": traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if (traffic and dom_ms) else None,
+            "hbm_peak_GBs": HBM_PEAK_GBS,
+            "note": "achieved = the reference's algorithm in FLOPs (SURVEY §8d: 0.83 GFLOP per [[1270,28]] codeword for 10 "
+                    "iterations) / this run's HIP-event launch time, against the 157.3 TFLOP/s f32 MFMA (= f32 vector) peak; "
+                    "frac is quoted only while profiles/traffic.json holds PMC counts of this kernel's sources at this shape "
+                    "(they say which pipe the time went to: fp32_lane_busy_frac = (32 cycles x MFMAs + 2 cycles x VALU "
+                    "wave-instructions) / (1024 SIMDs x 2.4 GHz x time)); executed_flops_per_launch = what the factored "
+                    "association executes for the same function"}
+
+
+def feedback_gnn_roofline(code_name, dims, launches, B, factored, stream):
+    """`roofline.gnn` of the c3 / c4 lines: the feedback-GNN launch, priced against VALU issue (streaming kernel, the default) or against
+    the f32 MFMA peak in the reference's FLOPs (MFMA-tile kernel)."""
+    import numpy as np
+    n, _, E = dims
+    gnn = [ms for ms, it, b in launches if it == PROF_TAG_GNN and b == B]
+    gnn_ms = float(np.mean(gnn)) if gnn else None
+    gnn_flops = gnn_flops_per_codeword(n, E) * B
+    gnn_exec = (gnn_flops_per_codeword_factored(n, E) if factored else gnn_flops_per_codeword(n, E)) * B
+    gnn_tf = gnn_flops / (gnn_ms * 1e-3) / 1e12 if gnn_ms else None
+    gent, gsrc = pmc_entry("gnn", f"gnn_{code_name}_B{B}")
+    if gent and not factored:
+        gent, gsrc = None, "profiles/traffic.json holds the counts of the default (factored) association; this run times the literal one"
+    gvi = gent.get("valu_wave_insts_per_launch") if gent else None
+    entry_is_of_the_mfma_kernel = bool(gent and gent.get("mfma_insts_per_launch"))  # the streaming kernel issues no MFMA
+    if gent and entry_is_of_the_mfma_kernel == stream:
+        gent, gsrc, gvi = None, "profiles/traffic.json holds the counts of the other feedback-GNN kernel (MFMA tiles vs streaming VALU)", None
+    common = {"avg_launch_ms": gnn_ms, "launches_timed": len(gnn), "algorithmic_flops_per_launch": gnn_flops,
+              "executed_flops_per_launch": gnn_exec,
+              "reference_tflops": gnn_tf, "reference_tflops_frac_of_f32_peak": gnn_tf / GNN_PEAK_TFLOPS if gnn_tf else None,
+              "executed_frac": gnn_exec / (gnn_ms * 1e-3) / 1e12 / GNN_PEAK_TFLOPS if gnn_ms else None,
+              "traffic": gent.get("hbm_bytes_per_launch") if gent else None,
+              "mfma_insts_per_launch": gent.get("mfma_insts_per_launch") if gent else None,
+              "valu_wave_insts_per_launch": gvi, "traffic_source": gsrc}
+    if stream:
+        # the default: factored association on the streaming VALU kernel (no MFMA: on gfx950 an f32 MFMA has the f32 VALU's rate and
+        # only pads the 40 / 20 / 3-row layers to 16-row tiles).  Priced like the BP4 kernel: VALU wave-instructions per second.
+        g_ach = gvi / (gnn_ms * 1e-3) / 1e9 if (gvi and gnn_ms) else None
+        return dict({"bound": "valu", "kernel": f"feedback-GNN streaming VALU kernel (factored association), B={B}",
+                     "achieved": g_ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                     "frac": g_ach / VALU_PEAK_GINST if g_ach else None}, **common,
+                    note="frac = SQ_INSTS_VALU per launch (offline PMC pass, source-fingerprinted) / this run's launch time / "
+                         "(1024 SIMDs x 2.4 GHz / 2); `reference_tflops` prices the reference's algorithm (SURVEY §8d: 13.4 MFLOP per "
+                         "[[882,24]] codeword, one 40->20 Dense per EDGE) per second, `executed_frac` the FLOPs the factored "
+                         "association executes, both against the 157.3 TFLOP/s f32 peak")
+    return dict({"bound": "mfma", "kernel": f"feedback-GNN MFMA-tile kernel ({'factored' if factored else 'literal'} association), B={B}",
+                 "achieved": gnn_tf, "peak": GNN_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": gnn_tf / GNN_PEAK_TFLOPS if gnn_tf else None}, **common,
+                note="`achieved` prices the reference's algorithm (SURVEY §8d: 13.4 MFLOP per [[882,24]] codeword, one 40->20 "
+                     "Dense per EDGE) against the f32 MFMA peak; the factored association executes `executed_flops_per_launch` "
+                     "(one 40->20 Dense per qubit and side) for the same function")
+
+
+def sandwich_roofline(code_name, dims, launches, launches_per_step, B, iters, factored, stream, shared_lse):
+    """`roofline` of the c3 / c4 lines: the first decoder's BP4 launch against VALU issue (utilisation) and against the hardware
+    transcendental rate (algorithmic efficiency), the SURVEY §8d streaming figure as an effective bandwidth, measured HBM bytes."""
+    import numpy as np
+    n, m, E = dims
+    # launches of a step arrive in order: BP4 (first decoder), then (feedback GNN, BP4) per further layer
+    per_step = [launches[i:i + launches_per_step] for i in range(0, len(launches), launches_per_step)]
+    dom = [s[0][0] for s in per_step if len(s) == launches_per_step and s[0][1] == iters[0] and s[0][2] == B]
+    dom_ms = float(np.mean(dom)) if dom else None
+    later = [ms for s in per_step if len(s) == launches_per_step for (ms, it, b) in s[2::2]]
+    alg_bytes = algorithmic_bytes_per_codeword(n, m, E, iters[0]) * B
+    eff_gbs = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
+    # VALU instruction counts and HBM bytes per launch are NOT measured by this run: they come from the rocprofv3 PMC passes of
+    # tools/refresh_traffic.sh at the same shape, guarded by the fingerprint of the kernel sources (pmc_entry)
+    ent, tsrc = pmc_entry("bp4", f"bp4_{code_name}_it{iters[0]}_B{B}")
+    if ent and not shared_lse:
+        ent, tsrc = None, "profiles/traffic.json holds the counts of the default (shared log-sum-exp) form; this run times the literal form"
+    traffic = ent.get("hbm_bytes_per_launch") if ent else None
+    vi = ent.get("valu_wave_insts_per_launch") if ent else None
+    achieved = vi / (dom_ms * 1e-3) / 1e9 if (vi and dom_ms) else None
+    n_exp, n_log = bp4_transcendentals_per_codeword(n, m, E, iters[0], shared_lse)
+    trans = (n_exp + n_log) * B
+    return {"bound": "valu",
+            "kernel": f"bp4_kernel<boxplus-phi>, first decoder (constant channel LLR), {iters[0]} iterations, B={B}",
+            "achieved": achieved, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+            "frac": achieved / VALU_PEAK_GINST if achieved else None,
+            "traffic": traffic, "traffic_source": tsrc,
+            "valu_wave_insts_per_launch": vi,
+            "library_is_the_profiled_binary": ent.get("library_is_the_profiled_binary") if ent else None,
+            "avg_launch_ms": dom_ms, "launches_timed": len(dom),
+            "later_decoders_avg_launch_ms": float(np.mean(later)) if later else None,
+            "transcendental_evals_per_launch": trans,
+            "transcendental_evals_per_codeword": {"exp": n_exp, "log": n_log},
+            "hw_transcendental_peak_per_s": HW_TRANSCENDENTAL_PEAK,
+            "frac_of_hw_transcendental_rate": trans / (dom_ms * 1e-3) / HW_TRANSCENDENTAL_PEAK if dom_ms else None,
+            "valu_insts_per_transcendental": vi * 64 / trans if vi else None,
+            "hbm_frac": traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if (traffic and dom_ms) else None,
+            "effective_bandwidth_frac": eff_gbs / HBM_PEAK_GBS if eff_gbs else None,
+            "effective_bandwidth_GBs": eff_gbs, "hbm_peak_GBs": HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "gnn": feedback_gnn_roofline(code_name, dims, launches, B, factored, stream),
+            "note": "bound = VALU issue: all messages stay in LDS for the 64 iterations, the kernel issues the exp/log "
+                    "instruction streams of fgnn_math.h (DESIGN.md §4.1).  frac = SQ_INSTS_VALU per launch (offline PMC pass, "
+                    "source-fingerprinted) / this run's HIP-event launch time / (1024 SIMDs x 2.4 GHz / 2): issue UTILISATION of "
+                    "the library's own instruction stream, not algorithmic efficiency.  frac_of_hw_transcendental_rate = "
+                    "every exp and log of the fixed dataflow (transcendental_evals_per_launch) / launch time / the chip's "
+                    "quarter-rate v_exp_f32 / v_log_f32 rate: the software routines that make CPU and GPU bit-equal spend "
+                    "valu_insts_per_transcendental lane-instructions per evaluation where the hardware unit would spend one "
+                    "quarter-rate instruction.  effective_bandwidth_frac = SURVEY §8d streaming-model bytes / time / 8 TB/s (can "
+                    "exceed 1: nothing streams); hbm_frac = measured HBM bytes / time / 8 TB/s"}
+
+
+def gnnbp4_forms_agreement(g, wdev, sx, sz, num_iter, workspace):
+    """GNN_BP4 on the same syndromes under the factored (default) and the literal association, compared per sample.
+    make_hard_decision = argmin over (0, X, Z, Y) (gnn.py:359-367): a qubit whose two smallest candidates are closer than twice the
+    LLR tolerance may legitimately decide either way under a 1e-6 perturbation — with untrained (seeded) weights the marginals of
+    many qubits sit that close to the boundary.  A differing decision BEYOND the tolerance would be a defect."""
+    import torch
+    prev = g.gnn_factored
+    res = []
+    for f in (prev, False):
+        g.set_gnn_factored(f)
+        res.append(g.gnn_bp4_decode(wdev, sx, sz, num_iter, return_logits=False, workspace=workspace))
+    g.set_gnn_factored(prev)
+    a, b = res
+    d = (a["llr"] - b["llr"]).abs().flatten(1).max(1).values
+    X, Y, Z = a["llr"][:, 0], a["llr"][:, 1], a["llr"][:, 2]
+    cand = torch.stack([torch.zeros_like(X), X, Z, Y], -1).sort(-1).values
+    margin = cand[..., 1] - cand[..., 0]
+    qdiff = (a["x_hat"] != b["x_hat"]) | (a["z_hat"] != b["z_hat"])
+    return {"samples": int(sx.shape[0]), "decisions_differ": int(qdiff.any(1).sum()),
+            "decisions_differ_beyond_llr_tolerance": int((qdiff & (margin > 2e-4)).any(1).sum()),
+            "max_decision_margin_where_they_differ": float(margin[qdiff].max()) if bool(qdiff.any()) else 0.0,
+            "max_abs_dllr": float(d.max()), "samples_gt_1e_4": int((d > 1e-4).sum())}
+
+
+def sandwich_extras(g, model, code, decs, G, iters, B, p, seed, literal_value):
+    """`extras` of a single-GPU c3 / c4 run: the variants that are NOT the headline — BP4 alone (configs[1]), the product default (exact
+    shortcuts, compaction: identical outputs) and the opt-in hardware-transcendental BP4 with its measured distance from the exact kernel."""
+    import numpy as np
+    import torch
+    import feedback_gnn_amd as F
+    L0 = model._llr_const(p)
+    ex, ez = g.pauli_noise(seed, p, 0, B)
+    sx, sz = g.syndrome(ex, ez)
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps
+
+    t_bp = timed(lambda: g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0))
+    g.set_saturation_shortcut(True)
+    t_bp_s = timed(lambda: g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0))
+    cs = torch.zeros(3, dtype=torch.int64, device="cuda")
+    t_s = timed(lambda: model.mc_step(B, p, cs))
+    g.set_saturation_shortcut(False)
+    model_c = F.Sandwich_BP_GNN_Evaluation_Model(code, decs, [G] * (len(iters) - 1), num_layers=len(iters), p0=0.05, seed=seed, compact=True)
+    cc = torch.zeros(3, dtype=torch.int64, device="cuda")
+    t_c = timed(lambda: model_c.mc_step(B, p, cc))
+    g.set_saturation_shortcut(True)
+    t_cs = timed(lambda: model_c.mc_step(B, p, cc))
+    g.set_saturation_shortcut(False)
+    # OPT-IN variant, never the headline: the phi rule on v_exp_f32 / v_log_f32 (FGNN_OPT_HW_TRANSCENDENTALS), and how
+    # far its results are from the exact kernel's on this very batch — the measured price of bit-exactness
+    exact = g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0)
+    g.set_hw_transcendentals(True)
+    t_hw = timed(lambda: g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0))
+    hw = g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0)
+    g.set_hw_transcendentals(False)
+    same_dec = ((exact["x_hat"] == hw["x_hat"]).all(1) & (exact["z_hat"] == hw["z_hat"]).all(1))
+    ones = torch.ones(B, dtype=torch.uint8, device="cuda")
+    conv_e = g.flag_update(exact["x_hat"], exact["z_hat"], sx, sz, ones.clone()) == 0
+    conv_h = g.flag_update(hw["x_hat"], hw["z_hat"], sx, sz, ones.clone()) == 0
+    both = conv_e & conv_h
+    dl = (exact["llr"] - hw["llr"]).abs().flatten(1).max(1).values
+    nb = max(int(both.sum()), 1)
+    # decisions that differ by a stabilizer (difference in the row space of hx / hz <=> zero syndrome under hx_perp / hz_perp)
+    hxp = torch.from_numpy(np.asarray(code.hx_perp)).to("cuda").float()
+    hzp = torch.from_numpy(np.asarray(code.hz_perp)).to("cuda").float()
+    dxb, dzb = (exact["x_hat"] ^ hw["x_hat"])[both].float(), (exact["z_hat"] ^ hw["z_hat"])[both].float()
+    same_class = ~(((dxb @ hxp.t()) % 2).bool().any(1) | ((dzb @ hzp.t()) % 2).bool().any(1))
+    hw_info = {"cw_per_s": B / t_hw, "speedup_vs_exact_kernel": t_bp / t_hw,
+               "samples": B, "converged_exact": int(conv_e.sum()), "converged_hw": int(conv_h.sum()),
+               "identical_decisions_all_samples": float(same_dec.float().mean()),
+               "identical_decisions_on_samples_both_converge": float(same_dec[both].float().mean()) if int(both.sum()) else None,
+               "same_correction_class_on_samples_both_converge": float(same_class.double().mean()) if int(both.sum()) else None,
+               "max_abs_llr_diff_le_1e-4_on_samples_both_converge": float((dl[both] <= 1e-4).sum()) / nb,
+               "median_abs_llr_diff_on_samples_both_converge": float(dl[both].median()) if int(both.sum()) else None}
+    return {"bp4_only_cw_per_s (configs[1])": B / t_bp,
+            "bp4_only_HW_TRANSCENDENTALS_opt_in_NOT_bit_exact (v_exp_f32/v_log_f32, phi clip points pinned, fixed dataflow)": hw_info,
+            "bp4_only_product_default_cw_per_s (exact saturation shortcut + fixed-point exit, identical outputs)": B / t_bp_s,
+            "sandwich_product_default_cw_per_s (exact saturation shortcut + fixed-point exit, identical outputs)": B / t_s,
+            "sandwich_compacted_cw_per_s (feedback rounds only on flagged samples, same outputs)": B / t_c,
+            "sandwich_compacted_product_default_cw_per_s (all exact optimisations, same outputs)": B / t_cs,
+            "sandwich_literal_forms_cw_per_s (now the top-level literal_forms object)": literal_value}
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
@@ -607,21 +831,9 @@ def main():
         common = {"value": value, "unit": "codewords/s", "n_gpus": world, "steps": K, "warmup": W,
                   "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                   "dtype": "f32", "data": "synthetic"}
+        counts_obj = {"flagged": int(cnt[0]), "block_errors": int(cnt[1]), "samples": int(cnt[2])}
         if is_c5:
-            dom = [ms for ms, it, b in launches if it == PROF_TAG_GNNBP4 and b == B]
-            dom_ms = float(np.mean(dom)) if dom else None
-            flops = gnnbp4_flops_per_codeword(n, m, E, iters[0]) * B
-            tf = flops / (dom_ms * 1e-3) / 1e12 if dom_ms else None
-            ent, tsrc = pmc_entry("gnnbp4", f"gnnbp4_{args.code}_it{iters[0]}_B{B}")
-            if ent and not factored:
-                ent, tsrc = None, "profiles/traffic.json holds the counts of the default (factored) association; this run times the literal one"
-            traffic = ent.get("hbm_bytes_per_launch") if ent else None
-            vi = ent.get("valu_wave_insts_per_launch") if ent else None
-            mi = ent.get("mfma_insts_per_launch") if ent else None
-            uses_mfma = bool(mi) if ent else None
-            lanes = (mi * 32 + vi * 2) / (1024 * 2.4e9 * dom_ms * 1e-3) if (ent and dom_ms and mi is not None and vi is not None) else None
-            out = dict({
-                "metric": "decoded codewords/sec, [[1270,28]] GNN_BP4 full-GNN decoder, 10 iterations"}, **common, **{
+            out = dict({"metric": "decoded codewords/sec, [[1270,28]] GNN_BP4 full-GNN decoder, 10 iterations"}, **common, **{
                 "config": {"workload": f"{code.name} GNN_BP4(num_embed_dims=20, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, "
                                        f"num_iter={iters[0]}, mean, tanh, use_bias) with seeded glorot weights (the reference ships none), "
                                        f"depolarizing p={args.p}, noise+syndrome+decode+residual+count on device (BASELINE.json {CONFIGS['c5']['baseline']})",
@@ -629,90 +841,14 @@ def main():
                            "parallelism": f"batch-sharded x{world}, no data-path collective", "seed": SEED,
                            "gnn_association": "factored" if factored else "literal"},
                 "per_rank_ms": per_rank_ms,
-                "roofline": {"bound": "mfma" if (uses_mfma or uses_mfma is None) else "valu",
-                             "kernel": f"GNN_BP4 kernel, {iters[0]} iterations, B={B}",
-                             "achieved": tf, "peak": GNN_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": (tf / GNN_PEAK_TFLOPS if tf else None) if ent else None,
-                             "reference_tflops": tf, "reference_tflops_frac_of_f32_peak": tf / GNN_PEAK_TFLOPS if tf else None,
-                             "algorithmic_flops_per_launch": flops,
-                             "executed_flops_per_launch": gnnbp4_flops_per_codeword_factored(n, m, E, iters[0]) * B if factored else None,
-                             "traffic": traffic, "traffic_source": tsrc,
-                             "mfma_insts_per_launch": mi, "valu_wave_insts_per_launch": vi,
-                             "fp32_lane_busy_frac": lanes,
-                             "mfma_pipe_busy_frac": mi * 32 / (1024 * 2.4e9 * dom_ms * 1e-3) if (ent and dom_ms and mi is not None) else None,
-                             "library_is_the_profiled_binary": ent.get("library_is_the_profiled_binary") if ent else None,
-                             "avg_launch_ms": dom_ms, "launches_timed": len(dom),
-                             "hbm_frac": traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if (traffic and dom_ms) else None,
-                             "hbm_peak_GBs": HBM_PEAK_GBS,
-                             "note": "achieved = the reference's algorithm in FLOPs (SURVEY §8d: 0.83 GFLOP per [[1270,28]] codeword for 10 "
-                                     "iterations) / this run's HIP-event launch time, against the 157.3 TFLOP/s f32 MFMA (= f32 vector) peak; "
-                                     "frac is quoted only while profiles/traffic.json holds PMC counts of this kernel's sources at this shape "
-                                     "(they say which pipe the time went to: fp32_lane_busy_frac = (32 cycles x MFMAs + 2 cycles x VALU "
-                                     "wave-instructions) / (1024 SIMDs x 2.4 GHz x time)); executed_flops_per_launch = what the factored "
-                                     "association executes for the same function"},
-                "counts": {"flagged": int(cnt[0]), "block_errors": int(cnt[1]), "samples": int(cnt[2])}})
+                "roofline": gnnbp4_roofline(args.code, (n, m, E), launches, B, iters[0], factored),
+                "counts": counts_obj})
         else:
-            L = len(iters)
-            # launches of a step arrive in order: BP4 (first decoder), then (feedback GNN, BP4) per further layer
-            per_step = [launches[i:i + launches_per_step] for i in range(0, len(launches), launches_per_step)]
-            dom = [s[0][0] for s in per_step if len(s) == launches_per_step and s[0][1] == iters[0] and s[0][2] == B]
-            dom_ms = float(np.mean(dom)) if dom else None
-            alg_bytes = algorithmic_bytes_per_codeword(n, m, E, iters[0]) * B
-            eff_gbs = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
-            gnn = [ms for ms, it, b in launches if it == PROF_TAG_GNN and b == B]
-            gnn_ms = float(np.mean(gnn)) if gnn else None
-            later = [ms for s in per_step if len(s) == launches_per_step for (ms, it, b) in s[2::2]]
-            gnn_flops = gnn_flops_per_codeword(n, E) * B
-            gnn_exec = (gnn_flops_per_codeword_factored(n, E) if factored else gnn_flops_per_codeword(n, E)) * B
-            gnn_tf = gnn_flops / (gnn_ms * 1e-3) / 1e12 if gnn_ms else None
-            # VALU instruction counts and HBM bytes per launch are NOT measured by this run: they come from the rocprofv3 PMC passes of
-            # tools/refresh_traffic.sh at the same shape, guarded by the fingerprint of the kernel sources (pmc_entry)
-            ent, tsrc = pmc_entry("bp4", f"bp4_{args.code}_it{iters[0]}_B{B}")
-            if ent and not shared_lse:
-                ent, tsrc = None, "profiles/traffic.json holds the counts of the default (shared log-sum-exp) form; this run times the literal form"
-            traffic = ent.get("hbm_bytes_per_launch") if ent else None
-            vi = ent.get("valu_wave_insts_per_launch") if ent else None
-            achieved = vi / (dom_ms * 1e-3) / 1e9 if (vi and dom_ms) else None
-            n_exp, n_log = bp4_transcendentals_per_codeword(n, m, E, iters[0], shared_lse)
-            trans = (n_exp + n_log) * B
-            gent, gsrc = pmc_entry("gnn", f"gnn_{args.code}_B{B}")
-            if gent and not factored:
-                gent, gsrc = None, "profiles/traffic.json holds the counts of the default (factored) association; this run times the literal one"
-            gvi = gent.get("valu_wave_insts_per_launch") if gent else None
-            entry_is_of_the_mfma_kernel = bool(gent and gent.get("mfma_insts_per_launch"))  # the streaming kernel issues no MFMA
-            if gent and entry_is_of_the_mfma_kernel == stream:
-                gent, gsrc, gvi = None, "profiles/traffic.json holds the counts of the other feedback-GNN kernel (MFMA tiles vs streaming VALU)", None
-            gnn_common = {"avg_launch_ms": gnn_ms, "launches_timed": len(gnn), "algorithmic_flops_per_launch": gnn_flops,
-                          "executed_flops_per_launch": gnn_exec,
-                          "reference_tflops": gnn_tf, "reference_tflops_frac_of_f32_peak": gnn_tf / GNN_PEAK_TFLOPS if gnn_tf else None,
-                          "executed_frac": gnn_exec / (gnn_ms * 1e-3) / 1e12 / GNN_PEAK_TFLOPS if gnn_ms else None,
-                          "traffic": gent.get("hbm_bytes_per_launch") if gent else None,
-                          "mfma_insts_per_launch": gent.get("mfma_insts_per_launch") if gent else None,
-                          "valu_wave_insts_per_launch": gvi, "traffic_source": gsrc}
-            if stream:
-                # the default: factored association on the streaming VALU kernel (no MFMA: on gfx950 an f32 MFMA has the f32 VALU's rate and
-                # only pads the 40 / 20 / 3-row layers to 16-row tiles).  Priced like the BP4 kernel: VALU wave-instructions per second.
-                g_ach = gvi / (gnn_ms * 1e-3) / 1e9 if (gvi and gnn_ms) else None
-                gnn_roofline = dict({"bound": "valu", "kernel": f"feedback-GNN streaming VALU kernel (factored association), B={B}",
-                                     "achieved": g_ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-                                     "frac": g_ach / VALU_PEAK_GINST if g_ach else None}, **gnn_common)
-                gnn_roofline["note"] = ("frac = SQ_INSTS_VALU per launch (offline PMC pass, source-fingerprinted) / this run's launch time / "
-                                        "(1024 SIMDs x 2.4 GHz / 2); `reference_tflops` prices the reference's algorithm (SURVEY §8d: 13.4 MFLOP per "
-                                        "[[882,24]] codeword, one 40->20 Dense per EDGE) per second, `executed_frac` the FLOPs the factored "
-                                        "association executes, both against the 157.3 TFLOP/s f32 peak")
-            else:
-                gnn_roofline = dict({"bound": "mfma", "kernel": f"feedback-GNN MFMA-tile kernel ({'factored' if factored else 'literal'} association), B={B}",
-                                     "achieved": gnn_tf, "peak": GNN_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                     "frac": gnn_tf / GNN_PEAK_TFLOPS if gnn_tf else None}, **gnn_common)
-                gnn_roofline["note"] = ("`achieved` prices the reference's algorithm (SURVEY §8d: 13.4 MFLOP per [[882,24]] codeword, one 40->20 "
-                                        "Dense per EDGE) against the f32 MFMA peak; the factored association executes `executed_flops_per_launch` "
-                                        "(one 40->20 Dense per qubit and side) for the same function")
             cfg = CONFIGS[args.config]
             is_cfg_shape = args.code == cfg["code"] and args.iters == cfg["iters"]
-            out = dict({
-                "metric": "decoded codewords/sec, [[882,24]] 64-iter BP4 + feedback-GNN" if args.code == "ghp882"
-                else "decoded codewords/sec, [[1270,28]] BP4 64+64 iters w/ feedback-GNN"}, **common, **{
-                "config": {"workload": f"{code.name} sandwich BP4-{'+'.join(map(str, iters))} with {L - 1} feedback-GNN "
+            out = dict({"metric": "decoded codewords/sec, [[882,24]] 64-iter BP4 + feedback-GNN" if args.code == "ghp882"
+                        else "decoded codewords/sec, [[1270,28]] BP4 64+64 iters w/ feedback-GNN"}, **common, **{
+                "config": {"workload": f"{code.name} sandwich BP4-{'+'.join(map(str, iters))} with {len(iters) - 1} feedback-GNN "
                                        f"pass(es), trained weights {wname}, boxplus-phi, factor 1.0, p0=0.05, depolarizing p={args.p}, "
                                        f"noise+syndrome+decode+residual+count on device (BASELINE.json "
                                        f"{cfg['baseline'] if is_cfg_shape else 'shape given on the command line'})",
@@ -723,35 +859,8 @@ def main():
                            "gnn_kernel": "streaming VALU" if stream else "MFMA tiles",
                            "bp4_qubit_update_lse": "shared per qubit side" if shared_lse else "per edge (literal)"},
                 "per_rank_ms": per_rank_ms,
-                "roofline": {"bound": "valu",
-                             "kernel": f"bp4_kernel<boxplus-phi>, first decoder (constant channel LLR), {iters[0]} iterations, B={B}",
-                             "achieved": achieved, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-                             "frac": achieved / VALU_PEAK_GINST if achieved else None,
-                             "traffic": traffic, "traffic_source": tsrc,
-                             "valu_wave_insts_per_launch": vi,
-                             "library_is_the_profiled_binary": ent.get("library_is_the_profiled_binary") if ent else None,
-                             "avg_launch_ms": dom_ms, "launches_timed": len(dom),
-                             "later_decoders_avg_launch_ms": float(np.mean(later)) if later else None,
-                             "transcendental_evals_per_launch": trans,
-                             "transcendental_evals_per_codeword": {"exp": n_exp, "log": n_log},
-                             "hw_transcendental_peak_per_s": HW_TRANSCENDENTAL_PEAK,
-                             "frac_of_hw_transcendental_rate": trans / (dom_ms * 1e-3) / HW_TRANSCENDENTAL_PEAK if dom_ms else None,
-                             "valu_insts_per_transcendental": vi * 64 / trans if vi else None,
-                             "hbm_frac": traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if (traffic and dom_ms) else None,
-                             "effective_bandwidth_frac": eff_gbs / HBM_PEAK_GBS if eff_gbs else None,
-                             "effective_bandwidth_GBs": eff_gbs, "hbm_peak_GBs": HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_launch": alg_bytes,
-                             "gnn": gnn_roofline,
-                             "note": "bound = VALU issue: all messages stay in LDS for the 64 iterations, the kernel issues the exp/log "
-                                     "instruction streams of fgnn_math.h (DESIGN.md §4.1).  frac = SQ_INSTS_VALU per launch (offline PMC pass, "
-                                     "source-fingerprinted) / this run's HIP-event launch time / (1024 SIMDs x 2.4 GHz / 2): issue UTILISATION of "
-                                     "the library's own instruction stream, not algorithmic efficiency.  frac_of_hw_transcendental_rate = "
-                                     "every exp and log of the fixed dataflow (transcendental_evals_per_launch) / launch time / the chip's "
-                                     "quarter-rate v_exp_f32 / v_log_f32 rate: the software routines that make CPU and GPU bit-equal spend "
-                                     "valu_insts_per_transcendental lane-instructions per evaluation where the hardware unit would spend one "
-                                     "quarter-rate instruction.  effective_bandwidth_frac = SURVEY §8d streaming-model bytes / time / 8 TB/s (can "
-                                     "exceed 1: nothing streams); hbm_frac = measured HBM bytes / time / 8 TB/s"},
-                "counts": {"flagged": int(cnt[0]), "block_errors": int(cnt[1]), "samples": int(cnt[2])}})
+                "roofline": sandwich_roofline(args.code, (n, m, E), launches, launches_per_step, B, iters, factored, stream, shared_lse),
+                "counts": counts_obj})
         if literal is not None:
             out["literal_forms"] = literal
         else:
@@ -764,25 +873,7 @@ def main():
         ex, ez = g.pauli_noise(SEED, args.p, first_timed, B)
         sx, sz = g.syndrome(ex, ez)
         if is_c5:
-            prev = g.gnn_factored
-            res = []
-            for f in (prev, False):
-                g.set_gnn_factored(f)
-                res.append(g.gnn_bp4_decode(wdev, sx, sz, iters[0], return_logits=False, workspace=ws))
-            g.set_gnn_factored(prev)
-            a, b = res
-            d = (a["llr"] - b["llr"]).abs().flatten(1).max(1).values
-            # make_hard_decision = argmin over (0, X, Z, Y) (gnn.py:359-367): a qubit whose two smallest candidates are closer than
-            # twice the LLR tolerance may legitimately decide either way under a 1e-6 perturbation — with untrained (seeded) weights
-            # the marginals of many qubits sit that close to the boundary.  A differing decision BEYOND the tolerance would be a defect.
-            X, Y, Z = a["llr"][:, 0], a["llr"][:, 1], a["llr"][:, 2]
-            cand = torch.stack([torch.zeros_like(X), X, Z, Y], -1).sort(-1).values
-            margin = cand[..., 1] - cand[..., 0]
-            qdiff = (a["x_hat"] != b["x_hat"]) | (a["z_hat"] != b["z_hat"])
-            fa = {"samples": B, "decisions_differ": int(qdiff.any(1).sum()),
-                  "decisions_differ_beyond_llr_tolerance": int((qdiff & (margin > 2e-4)).any(1).sum()),
-                  "max_decision_margin_where_they_differ": float(margin[qdiff].max()) if bool(qdiff.any()) else 0.0,
-                  "max_abs_dllr": float(d.max()), "samples_gt_1e_4": int((d > 1e-4).sum())}
+            fa = gnnbp4_forms_agreement(g, wdev, sx, sz, iters[0], ws)
         else:
             fa = g.forms_agreement(sx, sz, iters, [G.device_weights] * (len(iters) - 1), llr_const(0.05))
         fa["p"] = args.p
@@ -817,65 +908,7 @@ def main():
         if "cpu_baseline_tf_like" in out:
             out["speedup_vs_cpu_tf_like"] = value / out["cpu_baseline_tf_like"]["value"]
         if not args.no_extras and not is_c5:
-            L0 = model._llr_const(args.p)
-            ex, ez = g.pauli_noise(SEED, args.p, 0, B)
-            sx, sz = g.syndrome(ex, ez)
-
-            def timed(fn, reps=3):
-                fn()
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                for _ in range(reps):
-                    fn()
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t) / reps
-
-            t_bp = timed(lambda: g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0))
-            g.set_saturation_shortcut(True)
-            t_bp_s = timed(lambda: g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0))
-            cs = torch.zeros(3, dtype=torch.int64, device="cuda")
-            t_s = timed(lambda: model.mc_step(B, args.p, cs))
-            g.set_saturation_shortcut(False)
-            model_c = F.Sandwich_BP_GNN_Evaluation_Model(code, decs, [G] * (len(iters) - 1), num_layers=len(iters), p0=0.05,
-                                                         seed=SEED, compact=True)
-            cc = torch.zeros(3, dtype=torch.int64, device="cuda")
-            t_c = timed(lambda: model_c.mc_step(B, args.p, cc))
-            g.set_saturation_shortcut(True)
-            t_cs = timed(lambda: model_c.mc_step(B, args.p, cc))
-            g.set_saturation_shortcut(False)
-            # OPT-IN variant, never the headline: the phi rule on v_exp_f32 / v_log_f32 (FGNN_OPT_HW_TRANSCENDENTALS), and how
-            # far its results are from the exact kernel's on this very batch — the measured price of bit-exactness
-            exact = g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0)
-            g.set_hw_transcendentals(True)
-            t_hw = timed(lambda: g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0))
-            hw = g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0)
-            g.set_hw_transcendentals(False)
-            same_dec = ((exact["x_hat"] == hw["x_hat"]).all(1) & (exact["z_hat"] == hw["z_hat"]).all(1))
-            ones = torch.ones(B, dtype=torch.uint8, device="cuda")
-            conv_e = g.flag_update(exact["x_hat"], exact["z_hat"], sx, sz, ones.clone()) == 0
-            conv_h = g.flag_update(hw["x_hat"], hw["z_hat"], sx, sz, ones.clone()) == 0
-            both = conv_e & conv_h
-            dl = (exact["llr"] - hw["llr"]).abs().flatten(1).max(1).values
-            nb = max(int(both.sum()), 1)
-            # decisions that differ by a stabilizer (difference in the row space of hx / hz <=> zero syndrome under hx_perp / hz_perp)
-            hxp = torch.from_numpy(np.asarray(code.hx_perp)).to("cuda").float()
-            hzp = torch.from_numpy(np.asarray(code.hz_perp)).to("cuda").float()
-            dxb, dzb = (exact["x_hat"] ^ hw["x_hat"])[both].float(), (exact["z_hat"] ^ hw["z_hat"])[both].float()
-            same_class = ~(((dxb @ hxp.t()) % 2).bool().any(1) | ((dzb @ hzp.t()) % 2).bool().any(1))
-            hw_info = {"cw_per_s": B / t_hw, "speedup_vs_exact_kernel": t_bp / t_hw,
-                       "samples": B, "converged_exact": int(conv_e.sum()), "converged_hw": int(conv_h.sum()),
-                       "identical_decisions_all_samples": float(same_dec.float().mean()),
-                       "identical_decisions_on_samples_both_converge": float(same_dec[both].float().mean()) if int(both.sum()) else None,
-                       "same_correction_class_on_samples_both_converge": float(same_class.double().mean()) if int(both.sum()) else None,
-                       "max_abs_llr_diff_le_1e-4_on_samples_both_converge": float((dl[both] <= 1e-4).sum()) / nb,
-                       "median_abs_llr_diff_on_samples_both_converge": float(dl[both].median()) if int(both.sum()) else None}
-            out["extras"] = {"bp4_only_cw_per_s (configs[1])": B / t_bp,
-                             "bp4_only_HW_TRANSCENDENTALS_opt_in_NOT_bit_exact (v_exp_f32/v_log_f32, phi clip points pinned, fixed dataflow)": hw_info,
-                             "bp4_only_product_default_cw_per_s (exact saturation shortcut + fixed-point exit, identical outputs)": B / t_bp_s,
-                             "sandwich_product_default_cw_per_s (exact saturation shortcut + fixed-point exit, identical outputs)": B / t_s,
-                             "sandwich_compacted_cw_per_s (feedback rounds only on flagged samples, same outputs)": B / t_c,
-                             "sandwich_compacted_product_default_cw_per_s (all exact optimisations, same outputs)": B / t_cs,
-                             "sandwich_literal_forms_cw_per_s (now the top-level literal_forms object)": out["literal_forms"]["value"]}
+            out["extras"] = sandwich_extras(g, model, code, decs, G, iters, B, args.p, SEED, out["literal_forms"]["value"])
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
