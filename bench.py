@@ -161,6 +161,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-build", action="store_true",
                     help="do not run make: only check that the libraries exist (profiled runs, child ranks)")
+    ap.add_argument("--no-literal", action="store_true",
+                    help="skip the literal-forms timing and the forms_agreement decode (profiled runs: the literal BP4 launches are the same "
+                         "kernel symbol with a runtime flag and would be averaged into the trace's per-kernel statistics)")
     ap.add_argument("--require-roofline", action="store_true",
                     help="exit non-zero (after printing the line) when roofline.frac is null: no offline PMC counts for this shape, "
                          "or counts measured on other kernel sources")
@@ -801,7 +804,7 @@ def main():
             counts = allreduce(counts, dist.ReduceOp.SUM)
         # ---- the same step with the reference's formulas term by term (both re-associations off), every rank, same bracket ----
         literal = None
-        if factored or (shared_lse and not is_c5):
+        if (factored or (shared_lse and not is_c5)) and not args.no_literal:
             g.set_gnn_factored(False)
             if not is_c5:
                 g.set_bp4_shared_lse(False)
@@ -863,11 +866,16 @@ def main():
                 "counts": counts_obj})
         if literal is not None:
             out["literal_forms"] = literal
+        elif args.no_literal:
+            out["literal_forms"] = None
         else:
             out["literal_forms"] = {"value": value, "ms_per_step": elapsed / K * 1e3, "unit": "codewords/s",
                                     "what": "the headline of this run IS the literal forms (FGNN_BENCH_BP4_LSE / FGNN_BENCH_GNN_ORDER = literal)"}
         out.update(cpu_out)
 
+    if rank == 0 and args.no_literal:
+        out["forms_agreement"] = None
+    elif rank == 0:
         # ---- per-sample agreement of the default forms with the literal ones on the first batch of the timed region ----
         first_timed = W * world * B  # rank 0's first timed batch starts at global sample W * world * B
         ex, ez = g.pauli_noise(SEED, args.p, first_timed, B)
@@ -908,7 +916,7 @@ def main():
         if "cpu_baseline_tf_like" in out:
             out["speedup_vs_cpu_tf_like"] = value / out["cpu_baseline_tf_like"]["value"]
         if not args.no_extras and not is_c5:
-            out["extras"] = sandwich_extras(g, model, code, decs, G, iters, B, args.p, SEED, out["literal_forms"]["value"])
+            out["extras"] = sandwich_extras(g, model, code, decs, G, iters, B, args.p, SEED, (out["literal_forms"] or {}).get("value"))
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()

@@ -286,11 +286,13 @@ def test_bench_starts_its_own_ranks():
     assert abs(d["value"] - 2 * 4096 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     # the same 8 192 global samples in one process give the same counters (sharding by global sample index)
     res1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4096",
-                           "--p", "0.1", "--cpu-sample", "0", "--no-extras", "--no-build"], stdout=subprocess.PIPE,
+                           "--p", "0.1", "--cpu-sample", "0", "--no-extras", "--no-build", "--no-literal"], stdout=subprocess.PIPE,
                           stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
     assert res1.returncode == 0, res1.stderr[-2000:]
     d1 = json.loads([l for l in res1.stdout.splitlines() if l.strip()][0])
     assert d1["counts"] == d["counts"] and d["counts"]["block_errors"] > 0
+    # --no-literal (profiled runs): no literal-forms region, no forms_agreement decode — and the line says so with nulls
+    assert d1["literal_forms"] is None and d1["forms_agreement"] is None and d["literal_forms"]["value"] > 0
 
 
 @pytest.mark.gpu
