@@ -629,6 +629,7 @@ extern "C" int fgnn_feedback_gnn_backward(const fgnn_graph* g, const fgnn_weight
                                           void* stream)
 {
     if (!g || !w) return fgnn_fail(FGNN_ERR_ARG, "graph or weights is NULL");
+    if (B == 0) return FGNN_OK;  // an empty batch needs no buffers
     if (!llr || !logit_hx || !logit_hz || !synd_x || !synd_z || !grad_out || !node_in || !node_h2 || !node_d2 ||
         !edge_feat || !edge_h1 || !edge_d1 || !edge_dm)
         return fgnn_fail(FGNN_ERR_ARG, "buffer is NULL");
@@ -676,13 +677,13 @@ extern "C" int fgnn_feedback_gnn_backward_general(const fgnn_graph* g, const fgn
 {
     if (!g || !w) return fgnn_fail(FGNN_ERR_ARG, "graph or weights is NULL");
     if (!w->general) return fgnn_fail(FGNN_ERR_ARG, "fgnn_feedback_gnn_backward_general takes weights made by fgnn_weights_create_general");
+    if (B < 0) return fgnn_fail(FGNN_ERR_ARG, "B must be >= 0");
+    if (B == 0) return FGNN_OK;  // an empty batch needs no buffers (an empty torch tensor's data pointer is NULL)
     if (!llr || !logit_hx || !logit_hz || !synd_x || !synd_z || !grad_out || !acts || !deltas) return fgnn_fail(FGNN_ERR_ARG, "buffer is NULL");
     if (num_layers != w->gen.nl) return fgnn_fail(FGNN_ERR_ARG, "num_layers must be 3 * num_mlp_layers (one activation / delta pair per Dense layer)");
     for (int li = 0; li < num_layers; ++li)
         if (!acts[li] || !deltas[li]) return fgnn_fail(FGNN_ERR_ARG, "buffer is NULL");
-    if (B < 0) return fgnn_fail(FGNN_ERR_ARG, "B must be >= 0");
     if (w->device != g->device) return fgnn_fail(FGNN_ERR_ARG, "weights and graph live on different devices");
-    if (B == 0) return FGNN_OK;
     FGNN_DEVICE_GUARD(g->device);
     GnnGenBwArgs a;
     std::memset(&a, 0, sizeof(a));

@@ -476,6 +476,16 @@ def test_empty_and_single_codeword_batches_through_every_entry_point():
     assert gb0["llr"].shape == (0, 3, g.n) and gb0["x_logit_all"].shape[:2] == (3, 0)
     s_b2, h_b2 = g.bp2_decode(torch.zeros((0, g.m_x), dtype=torch.uint8, device=g.device), 4, "boxplus-phi", 1.0, llr_const=-1.0)
     assert s_b2.shape == (0, g.n) and h_b2.shape == (0, g.n)
+    # the reverse passes (shipped and runtime-shaped) and the forms comparison on an empty batch
+    grads0 = g.feedback_gnn_backward(w, o0["llr"], o0["z_logit"], o0["x_logit"], sx0, sz0, o0["llr"])
+    assert len(grads0) == 12 and all(float(t.abs().sum()) == 0.0 for t in grads0)
+    from feedback_gnn_amd.graph import gnn_weight_shapes
+    cfg = (8, 16, 3, "sum", "relu", True)
+    wg = GnnWeights([rng.uniform(-0.3, 0.3, size=shp).astype(np.float32) for shp in gnn_weight_shapes(*cfg[:3], cfg[5])], g.device, config=cfg)
+    gradsg = g.feedback_gnn_backward(wg, o0["llr"], o0["z_logit"], o0["x_logit"], sx0, sz0, o0["llr"])
+    assert len(gradsg) == 18 and all(float(t.abs().sum()) == 0.0 for t in gradsg)
+    fa0 = g.forms_agreement(sx0, sz0, [8, 4], [w], L0)
+    assert fa0["samples"] == 0 and fa0["decisions_differ"] == 0 and fa0["max_abs_dllr"] == 0.0
     # B = 1 equals row 0 of B = 5
     ex, ez = g.pauli_noise(SEED, 0.1, 7, 5)
     sx, sz = g.syndrome(ex, ez)
