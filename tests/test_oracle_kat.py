@@ -304,3 +304,33 @@ def test_general_gnn_bp4_oracle_vs_numpy_restatement(name, cfg):
     assert np.abs(o["llr"] - r["llr"]).max() <= 2e-5 * scale
     assert np.abs(o["x_logit_all"] - r["x_logit_all"]).max() <= 5e-4 and np.abs(o["z_logit_all"] - r["z_logit_all"]).max() <= 5e-4
     assert (o["x_hat"] == r["x_hat"]).mean() > 0.98 and (o["z_hat"] == r["z_hat"]).mean() > 0.98
+
+
+def test_the_oracle_starts_literal_and_a_checker_must_name_its_forms():
+    """Round 4: the C oracle is created as the LITERAL restatement of the reference (one log-sum-exp per edge, decoding_q.py:254-273;
+    one Dense per edge, feedback_gnn.py:175-184); the re-associated forms libfgnn_hip runs by default are restated next to it and have
+    to be asked for.  OracleGraph has no default for `forms`: every checker says which restatement it compares against.  The two are
+    different float32 operation sequences of the same function: equal decisions on an easy batch, marginals that differ in the last
+    bits after ONE iteration from non-trivial messages."""
+    from oracle.oracle import OracleGraph
+    from helpers import WEIGHTS_882
+    from feedback_gnn_amd.weights_io import read_weight_list
+    c = code("gb48")
+    with pytest.raises(TypeError):
+        OracleGraph(c)
+    with pytest.raises(ValueError):
+        OracleGraph(c, forms="fast")
+    lit, lib = OracleGraph(c, forms="literal"), OracleGraph(c, forms="library-default")
+    assert (lit.gnn_factored, lit.vn_shared_lse, lib.gnn_factored, lib.vn_shared_lse) == (False, False, True, True)
+    ex, ez = lit.pauli_noise(0x5EED, 0.03, 0, 64)
+    sx, sz = lit.syndrome(ex, ez)
+    rng = np.random.RandomState(1)
+    init = (rng.uniform(-6, 6, size=(64, lit.E_x)).astype(np.float32), rng.uniform(-6, 6, size=(64, lit.E_z)).astype(np.float32))
+    a = lit.bp4_decode(sx, sz, 1, "minsum", 1.0, llr_const=llr_const(0.05), msg_init=init, return_msgs=True)
+    b = lib.bp4_decode(sx, sz, 1, "minsum", 1.0, llr_const=llr_const(0.05), msg_init=init, return_msgs=True)
+    d = np.abs(a["msg_x"] - b["msg_x"]).max()
+    assert 0 < d <= 4 * np.spacing(np.float32(np.abs(a["llr"]).max())), d
+    w = read_weight_list(WEIGHTS_882)
+    oa = lit.sandwich_decode(sx, sz, [32, 8], [w], llr_const(0.05))
+    ob = lib.sandwich_decode(sx, sz, [32, 8], [w], llr_const(0.05))
+    assert np.array_equal(oa["x_hat"], ob["x_hat"]) and np.array_equal(oa["z_hat"], ob["z_hat"])
