@@ -608,6 +608,16 @@ def sandwich_extras(g, model, code, decs, G, iters, B, p, seed, literal_value):
     g.set_saturation_shortcut(True)
     t_cs = timed(lambda: model_c.mc_step(B, p, cc))
     g.set_saturation_shortcut(False)
+    # the headline's fixed dataflow with consecutive batches alternating between two HIP streams (own workspaces, shared atomic counters)
+    model_2s = F.Sandwich_BP_GNN_Evaluation_Model(code, decs, [G] * (len(iters) - 1), num_layers=len(iters), p0=0.05, seed=seed, streams=2)
+    c2 = torch.zeros(3, dtype=torch.int64, device="cuda")
+
+    def two_stream_steps():
+        for _ in range(2):
+            model_2s.mc_step(B, p, c2)
+        model_2s.join()
+
+    t_2s = timed(two_stream_steps) / 2
     # OPT-IN variant, never the headline: the phi rule on v_exp_f32 / v_log_f32 (FGNN_OPT_HW_TRANSCENDENTALS), and how
     # far its results are from the exact kernel's on this very batch — the measured price of bit-exactness
     exact = g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0)
@@ -640,6 +650,8 @@ def sandwich_extras(g, model, code, decs, G, iters, B, p, seed, literal_value):
             "sandwich_product_default_cw_per_s (exact saturation shortcut + fixed-point exit, identical outputs)": B / t_s,
             "sandwich_compacted_cw_per_s (feedback rounds only on flagged samples, same outputs)": B / t_c,
             "sandwich_compacted_product_default_cw_per_s (all exact optimisations, same outputs)": B / t_cs,
+            "sandwich_two_streams_cw_per_s (fixed dataflow, Sandwich_BP_GNN_Evaluation_Model(streams=2): consecutive batches alternate between two "
+            "HIP streams; same samples, same counters)": B / t_2s,
             "sandwich_literal_forms_cw_per_s (now the top-level literal_forms object)": literal_value}
 
 

@@ -499,3 +499,35 @@ def test_empty_and_single_codeword_batches_through_every_entry_point():
     gb = g.gnn_bp4_decode(gw, sx, sz, 2)
     g1 = g.gnn_bp4_decode(gw, sx[:1].contiguous(), sz[:1].contiguous(), 2)
     assert torch.equal(g1["llr"][0], gb["llr"][0])
+
+
+def test_mc_step_on_two_streams_counts_the_same_samples():
+    """`Sandwich_BP_GNN_Evaluation_Model(streams=2)`: consecutive batches alternate between two side streams (own workspaces, shared
+    atomic counters) so that independent batches overlap on the chip.  Scheduling only: after `join()` the counters equal those of the
+    one-stream model over the same global samples, `mc_steps` after `mc_step` (shared workspaces) is ordered by the model itself, and a
+    caller's zeroing of the counters on its own stream is ordered before the next batch."""
+    from feedback_gnn_amd import QLDPCBPDecoder, Feedback_GNN, Sandwich_BP_GNN_Evaluation_Model, load_weights
+    from helpers import gpu_graph
+    c = code("ghp882")
+    g = gpu_graph("ghp882")
+    decs = [QLDPCBPDecoder(code=c, num_iter=it, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True, graph=g) for it in (24, 8)]
+    G = Feedback_GNN(code=c, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean", activation="tanh", use_bias=True, graph=g)
+    load_weights(G, WEIGHTS_882)
+    B, p, steps = 1500, 0.10, 7
+    res = {}
+    for streams in (1, 2, 3):
+        m = Sandwich_BP_GNN_Evaluation_Model(c, decs, [G], num_layers=2, seed=77, streams=streams)
+        counts = torch.zeros(3, dtype=torch.int64, device=g.device)
+        for _ in range(steps):
+            m.mc_step(B, p, counts)
+        m.join()
+        first = counts.clone()
+        counts.zero_()                      # on the caller's stream, after the join
+        m.mc_step(B, p, counts)             # must not start before the zeroing
+        ring = torch.zeros((2, 3), dtype=torch.int64, device=g.device)
+        m.mc_steps(B, p, 2, counts, ring)   # joins the side streams itself before it reuses a workspace
+        m.join()
+        torch.cuda.synchronize()
+        res[streams] = (first.tolist(), counts.tolist(), ring.tolist())
+    assert res[1][0][2] == steps * B and res[1][0][1] > 0
+    assert res[2] == res[1] and res[3] == res[1], res

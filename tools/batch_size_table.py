@@ -2,7 +2,8 @@
 residual + counters on device) at the reference's own batch sizes — n882.py:66 runs batch_size = 5 000, QLDPC.ipynb 10 000 — next to the
 65 536 the headline uses:   python tools/batch_size_table.py [out.json]
 Prints codewords/s per batch size and the fraction of the 65 536 rate; also `mc_steps` (k batches decoded as one launch, counters per
-batch boundary: what sim_ber uses to keep the reference's batch size at the full-chip rate)."""
+batch boundary: what sim_ber uses to keep the reference's batch size at the full-chip rate) and the bare `mc_step` loop of a model built
+with `streams=2` (consecutive batches alternate between two HIP streams)."""
 import json
 import sys
 import time
@@ -59,5 +60,24 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / 8
 extra = {"mc_steps_13x5000": {"cw_per_s": 65000 / dt, "ms": dt * 1e3, "frac_of_65536_rate": 65000 / dt / full}}
 print(f"mc_steps(5000, k = 13) [65 000 codewords as one launch, counters per 5 000]: {dt * 1e3:.2f} ms, {65000 / dt / 1e3:.1f} k codewords/s = {65000 / dt / full:.3f}")
+# Sandwich_BP_GNN_Evaluation_Model(streams=2): consecutive, independent batches issued alternately on two HIP streams (own workspaces,
+# shared atomic counters), so that one batch's kernels fill the SIMDs the other's prologues, epilogues and kernel tails leave idle
+m2s = F.Sandwich_BP_GNN_Evaluation_Model(c, [dec1, dec2], [G], num_layers=2, p0=0.05, seed=0x5EED, streams=2)
+two = []
+for B in (1024, 2048, 4096, 5000, 10000, 16384, 65536):
+    for _ in range(6):
+        m2s.mc_step(B, 0.01, counts)
+    m2s.join()
+    torch.cuda.synchronize()
+    reps = 2 * max(4, int(0.3 / (60e-3 * B / 65536 + 60e-6)))
+    t = time.perf_counter()
+    for _ in range(reps):
+        m2s.mc_step(B, 0.01, counts)
+    m2s.join()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / reps
+    two.append({"batch": B, "cw_per_s": B / dt, "ms_per_step": dt * 1e3, "frac_of_65536_rate": B / dt / full})
+    print(f"two streams, B = {B:6d}: {dt * 1e3:8.3f} ms per step, {B / dt / 1e3:8.1f} k codewords/s = {B / dt / full:.3f} of the 65 536 rate", flush=True)
+extra["two_streams"] = two
 if OUT:
     json.dump({"rows": rows, **extra}, open(OUT, "w"), indent=1)
