@@ -207,18 +207,20 @@ class Sandwich_BP_GNN_Evaluation_Model:
         self._next_sample += self.world_size * batch_size
         return first
 
-    def decode(self, batch_size, p, first_sample=None, noise=None):
+    def decode(self, batch_size, p, first_sample=None, noise=None, _slot=None):
         """Noise -> syndromes -> sandwich.  Returns dict(noise_x, noise_z, x_hat, z_hat).  ``noise=(noise_x, noise_z)``: decode
         given device arrays instead of drawing ``batch_size`` samples."""
         B = int(batch_size)
         g = self.graph
+        if _slot is None:  # a direct call runs on the caller's stream: behind whatever `mc_step` has in flight on the side streams
+            self.join()
         if noise is None:
             first = self._take_samples(B) if first_sample is None else int(first_sample)
             ex, ez = self.channel(B, p, first)
         else:
             ex, ez = noise
         sx, sz = g.syndrome(ex, ez)
-        k = self._slot if self.streams > 1 else 0
+        k = _slot if _slot is not None else 0
         if self._ws_batches[k] < B:  # the largest workspace seen serves every smaller batch
             self._workspaces[k] = g.sandwich_workspace(B)
             self._ws_batches[k] = B
@@ -265,7 +267,7 @@ class Sandwich_BP_GNN_Evaluation_Model:
             side = self._side_streams[self._slot]
             side.wait_stream(torch.cuda.current_stream(self.graph.device))  # whatever the caller queued (e.g. zeroing counts) comes first
             with torch.cuda.stream(side):
-                o = self.decode(batch_size, p)
+                o = self.decode(batch_size, p, _slot=self._slot)
                 _, _, flags = self.graph.residual(o["noise_x"], o["noise_z"], o["x_hat"], o["z_hat"], want_arrays=False)
                 self.graph.count_flags(flags, counts)  # atomic adds: batches in flight on several streams share the counters
             self._slot = (self._slot + 1) % self.streams

@@ -520,14 +520,16 @@ def test_mc_step_on_two_streams_counts_the_same_samples():
         counts = torch.zeros(3, dtype=torch.int64, device=g.device)
         for _ in range(steps):
             m.mc_step(B, p, counts)
+        s_hat, ls_hat = m(B, p)             # a direct call while batches are in flight: runs behind them on the caller's stream
         m.join()
         first = counts.clone()
+        direct = (int(s_hat.any(1).sum()), int(ls_hat.any(1).sum()))
         counts.zero_()                      # on the caller's stream, after the join
         m.mc_step(B, p, counts)             # must not start before the zeroing
         ring = torch.zeros((2, 3), dtype=torch.int64, device=g.device)
         m.mc_steps(B, p, 2, counts, ring)   # joins the side streams itself before it reuses a workspace
         m.join()
         torch.cuda.synchronize()
-        res[streams] = (first.tolist(), counts.tolist(), ring.tolist())
+        res[streams] = (first.tolist(), counts.tolist(), ring.tolist(), direct)
     assert res[1][0][2] == steps * B and res[1][0][1] > 0
     assert res[2] == res[1] and res[3] == res[1], res
