@@ -189,7 +189,7 @@ class Sandwich_BP_GNN_Evaluation_Model:
         # ``streams`` > 1: `mc_step` issues consecutive (independent) batches alternately on that many side streams, each with its own
         # workspace, so that one batch's kernels fill the SIMDs that the prologues, epilogues and kernel tails of the other leave idle —
         # at the reference's batch size of 5 000 the bare loop goes from 0.90 to 0.99 of the chip's large-batch rate
-        # (profiles/r4_batch_sizes.txt).  The counters are updated atomically on the device; `join()` orders the caller's stream
+        # (profiles/r4z_batch_sizes.txt).  The counters are updated atomically on the device; `join()` orders the caller's stream
         # behind all side streams (call it before reading the counters).
         self.streams = max(1, int(streams))
         self._side_streams = [torch.cuda.Stream(device=self.graph.device) for _ in range(self.streams)] if self.streams > 1 else []
