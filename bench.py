@@ -66,6 +66,8 @@ HW_TRANSCENDENTAL_PEAK = 1024 * 64 * 2.4e9 / 8  # 1.966e13 evaluations/s
 GNN_PEAK_TFLOPS = 157.3  # same guide: f32 MFMA (= f32 vector) peak
 
 CONFIGS = {
+    "c1": dict(code="ghp882", iters="32", batch=256, p=0.05, baseline="configs[0]: the reference's own CPU-runnable case"),
+    "c2": dict(code="ghp882", iters="64", batch=65536, baseline="configs[1]: BP4 alone"),
     "c3": dict(code="ghp882", iters="64,16", batch=65536, baseline="configs[2]"),
     "c4": dict(code="ghp1270", iters="64,64", batch=32768, baseline="configs[3], per-GPU shard 262 144 / 8"),
     "c5": dict(code="ghp1270", iters="10", batch=16384, baseline="configs[4], per-GPU shard 131 072 / 8"),
@@ -149,9 +151,10 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS),
-                    help="BASELINE.json configuration: c3 = configs[2] (headline), c4 = configs[3] shard, c5 = configs[4] shard (GNN_BP4)")
+                    help="BASELINE.json configuration: c3 = configs[2] (headline), c4 = configs[3] shard, c5 = configs[4] shard (GNN_BP4); "
+                         "c1 = configs[0] (BP4-32, 256 codewords, p = 0.05), c2 = configs[1] (BP4-64 alone)")
     ap.add_argument("--batch", type=int, default=None, help="codewords per GPU per step (default: the configuration's)")
-    ap.add_argument("--p", type=float, default=0.01)
+    ap.add_argument("--p", type=float, default=None, help="depolarizing probability (default: the configuration's, 0.01 unless it names one)")
     ap.add_argument("--code", default=None, choices=["ghp882", "ghp1270"], help="default: the configuration's")
     ap.add_argument("--iters", default=None, help="BP iterations per stage (c5: GNN_BP4 iterations); default: the configuration's")
     ap.add_argument("--cpu-sample", type=int, default=-1,
@@ -172,6 +175,7 @@ def parse_args(argv=None):
     args.batch = cfg["batch"] if args.batch is None else args.batch
     args.code = cfg["code"] if args.code is None else args.code
     args.iters = cfg["iters"] if args.iters is None else args.iters
+    args.p = cfg.get("p", 0.01) if args.p is None else args.p
     return args
 
 
@@ -541,7 +545,7 @@ def sandwich_roofline(code_name, dims, launches, launches_per_step, B, iters, fa
             "effective_bandwidth_frac": eff_gbs / HBM_PEAK_GBS if eff_gbs else None,
             "effective_bandwidth_GBs": eff_gbs, "hbm_peak_GBs": HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": alg_bytes,
-            "gnn": feedback_gnn_roofline(code_name, dims, launches, B, factored, stream),
+            "gnn": feedback_gnn_roofline(code_name, dims, launches, B, factored, stream) if len(iters) > 1 else None,
             "note": "bound = VALU issue: all messages stay in LDS for the 64 iterations, the kernel issues the exp/log "
                     "instruction streams of fgnn_math.h (DESIGN.md §4.1).  frac = SQ_INSTS_VALU per launch (offline PMC pass, "
                     "source-fingerprinted) / this run's HIP-event launch time / (1024 SIMDs x 2.4 GHz / 2): issue UTILISATION of "
@@ -861,10 +865,15 @@ def main():
         else:
             cfg = CONFIGS[args.config]
             is_cfg_shape = args.code == cfg["code"] and args.iters == cfg["iters"]
-            out = dict({"metric": "decoded codewords/sec, [[882,24]] 64-iter BP4 + feedback-GNN" if args.code == "ghp882"
-                        else "decoded codewords/sec, [[1270,28]] BP4 64+64 iters w/ feedback-GNN"}, **common, **{
-                "config": {"workload": f"{code.name} sandwich BP4-{'+'.join(map(str, iters))} with {len(iters) - 1} feedback-GNN "
-                                       f"pass(es), trained weights {wname}, boxplus-phi, factor 1.0, p0=0.05, depolarizing p={args.p}, "
+            nk = "[[882,24]]" if args.code == "ghp882" else "[[1270,28]]"
+            metric = (f"decoded codewords/sec, {nk} BP4 {iters[0]} iters" if len(iters) == 1 else
+                      "decoded codewords/sec, [[882,24]] 64-iter BP4 + feedback-GNN" if args.code == "ghp882" else
+                      "decoded codewords/sec, [[1270,28]] BP4 64+64 iters w/ feedback-GNN")
+            out = dict({"metric": metric}, **common, **{
+                "config": {"workload": (f"{code.name} BP4-{iters[0]} alone (one QLDPCBPDecoder launch per step), " if len(iters) == 1 else
+                                        f"{code.name} sandwich BP4-{'+'.join(map(str, iters))} with {len(iters) - 1} feedback-GNN "
+                                        f"pass(es), trained weights {wname}, ") +
+                                       f"boxplus-phi, factor 1.0, p0=0.05, depolarizing p={args.p}, "
                                        f"noise+syndrome+decode+residual+count on device (BASELINE.json "
                                        f"{cfg['baseline'] if is_cfg_shape else 'shape given on the command line'})",
                            "code": code.name, "batch_per_gpu": B, "global_batch": world * B, "bp_iters": iters, "p": args.p,

@@ -85,6 +85,11 @@ def test_config_shapes_and_the_algorithmic_counts_of_the_other_two_configs():
     import bench
     a = bench.parse_args([])
     assert (a.config, a.code, a.iters, a.batch) == ("c3", "ghp882", "64,16", 65536)
+    assert a.p == 0.01
+    a = bench.parse_args(["--config", "c1"])  # configs[0]: the reference's CPU-runnable case (32 iterations, 256 codewords, p = 0.05)
+    assert (a.code, a.iters, a.batch, a.p) == ("ghp882", "32", 256, 0.05) and bench.parse_args(["--config", "c1", "--p", "0.02"]).p == 0.02
+    a = bench.parse_args(["--config", "c2"])  # configs[1]: BP4-64 alone
+    assert (a.code, a.iters, a.batch, a.p) == ("ghp882", "64", 65536, 0.01)
     a = bench.parse_args(["--config", "c4"])
     assert (a.code, a.iters, a.batch) == ("ghp1270", "64,64", 32768) and 8 * a.batch == 262144
     a = bench.parse_args(["--config", "c5", "--batch", "128"])
@@ -144,6 +149,34 @@ def test_bench_lines_of_the_other_two_configs(config, batch):
 
 
 @pytest.mark.gpu
+def test_bench_lines_of_the_bp4_only_configs():
+    """`--config c1` (BASELINE configs[0]: BP4-32 on 256 codewords at p = 0.05 — at the configuration's own shape, so its PMC entry
+    applies and --require-roofline passes) and `--config c2` (configs[1]: BP4-64 alone; here at a batch without an entry): one decoder
+    launch per step, no feedback-GNN object in the roofline, the literal-forms leg and the per-sample agreement like the headline."""
+    import bench
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c1", "--steps", "4", "--warmup", "1", "--cpu-sample", "32",
+                          "--no-extras", "--require-roofline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    d = json.loads([l for l in res.stdout.splitlines() if l.strip()][0])
+    r = d["roofline"]
+    ent, _ = bench.pmc_entry("bp4", "bp4_ghp882_it32_B256")
+    assert res.returncode == (0 if ent else 5), res.stderr[-2000:]
+    assert d["metric"] == "decoded codewords/sec, [[882,24]] BP4 32 iters" and "configs[0]" in d["config"]["workload"]
+    assert d["config"]["bp_iters"] == [32] and d["config"]["p"] == 0.05 and d["config"]["batch_per_gpu"] == 256
+    assert r["gnn"] is None and r["launches_timed"] == 4 and r["later_decoders_avg_launch_ms"] is None
+    assert (r["frac"] is not None and 0 < r["frac"] <= 1) if ent else r["frac"] is None
+    assert d["cpu_baseline"]["gpu_matches_oracle_bit_exact"] is True and d["forms_agreement"]["samples"] == 256
+    assert d["counts"]["samples"] == 4 * 256 and 0 < d["literal_forms"]["value"] < 1.05 * d["value"]
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c2", "--steps", "2", "--warmup", "1", "--batch", "2048",
+                          "--cpu-sample", "32", "--no-extras", "--no-build"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.strip()][0])
+    assert d["metric"] == "decoded codewords/sec, [[882,24]] BP4 64 iters" and "BP4-64 alone" in d["config"]["workload"]
+    assert d["roofline"]["gnn"] is None and d["roofline"]["frac"] is None and d["forms_agreement"]["decisions_differ"] == 0
+    assert d["cpu_baseline"]["gpu_matches_oracle_bit_exact"] is True
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("config,batch", [("c4", 512), ("c5", 128)])
 def test_other_configs_shard_over_two_ranks(config, batch):
     """`--config c4 | c5 --gpus 2` (two ranks sharing the test box's GPU over gloo): the counters equal ONE process over the same 2 B
@@ -173,7 +206,8 @@ def test_roofline_counts_are_fingerprinted_and_the_fraction_is_a_fraction():
     from feedback_gnn_amd import _lib
     tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     # every BASELINE config's dominant kernel has an entry (round 4): no driver-runnable line prints a null fraction for want of one
-    for key in ("bp4_ghp882_it64_B65536", "gnn_ghp882_B65536", "bp4_ghp1270_it64_B32768", "gnn_ghp1270_B32768", "gnnbp4_ghp1270_it10_B16384"):
+    for key in ("bp4_ghp882_it32_B256", "bp4_ghp882_it64_B65536", "gnn_ghp882_B65536", "bp4_ghp1270_it64_B32768", "gnn_ghp1270_B32768",
+                "gnnbp4_ghp1270_it10_B16384"):
         assert key in tj, key
     for kind, key in (("bp4", "bp4_ghp882_it64_B65536"), ("gnn", "gnn_ghp882_B65536"), ("bp4", "bp4_ghp1270_it64_B32768"),
                       ("gnn", "gnn_ghp1270_B32768"), ("gnnbp4", "gnnbp4_ghp1270_it10_B16384")):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call that produces everything profiles/ cites for a round:  bash tools/final_profile.sh <tag>
-# (GPU tests; the PMC passes of all three BASELINE configurations -> traffic.json; the three bench lines; a rocprofv3 kernel trace of the
+# (GPU tests; the PMC passes of the BASELINE configurations -> traffic.json; the five bench lines; a rocprofv3 kernel trace of the
 # same bench commands; the batch-size table).  Copy what is to be judged from gpurun_out/<tag>/ into profiles/ afterwards.
 set -e
 TAG=${1:-r00}
@@ -11,11 +11,13 @@ export TMPDIR=/tmp
 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1 || { tail -30 $O/pytest_gpu.log; exit 1; }
 tail -2 $O/pytest_gpu.log
 # counts first: the bench lines below then quote THIS library's PMC passes (library_is_the_profiled_binary: true)
-bash tools/refresh_traffic.sh $TAG c3 c4 c5 > $O/refresh.log 2>&1
+bash tools/refresh_traffic.sh $TAG c1 c3 c4 c5 > $O/refresh.log 2>&1
 cp $O/traffic.json profiles/traffic.json
 python bench.py --no-build --require-roofline > $O/bench_c3.json 2> $O/bench.err
 python bench.py --no-build --config c4 --require-roofline > $O/bench_c4.json 2>> $O/bench.err
 python bench.py --no-build --config c5 --require-roofline > $O/bench_c5.json 2>> $O/bench.err
+python bench.py --no-build --config c1 --require-roofline > $O/bench_c1.json 2>> $O/bench.err
+python bench.py --no-build --config c2 --require-roofline > $O/bench_c2.json 2>> $O/bench.err
 cat $O/bench_c3.json
 # kernel traces of the same commands (no CPU legs, no extras, --no-literal: only the launches of the warm-up and of the timed region —
 # the literal-forms launches are the same BP4 symbol with a runtime flag and would be averaged into its statistics)
