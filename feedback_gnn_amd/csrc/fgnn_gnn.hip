@@ -25,6 +25,7 @@
 
 #include "fgnn_internal.h"
 #include "fgnn_math.h"
+#include "fgnn_pk.h"
 
 namespace {
 
@@ -370,6 +371,12 @@ constexpr int SROW = 32, EROW = 48;
 #ifndef FGNN_GNNS_WAVES
 #define FGNN_GNNS_WAVES 7
 #endif
+#ifndef FGNN_GNNS_LIT_UNROLL
+#define FGNN_GNNS_LIT_UNROLL 1  // measured: 13.4 ms at 1, 13.8 at 2, 13.7 at 4 ([[882,24]] x 65 536)
+#endif
+#ifndef FGNN_GNNS_LIT_WAVES
+#define FGNN_GNNS_LIT_WAVES 5  // the literal association keeps one more 20-wide accumulator alive per lane
+#endif
 #define FGNN_GNNS_OCC __attribute__((amdgpu_waves_per_eu(FGNN_GNNS_WAVES, FGNN_GNNS_WAVES)))
 
 struct MsgRow {
@@ -420,6 +427,50 @@ __device__ __forceinline__ void side_stream(scalar_fp rows, scalar_fp b2, const 
     for (int i = 0; i < MSG; ++i) feat[i] = (DV == 3 ? fg_div3(acc[i]) : acc[i] / (float)DV) + b2[i];
 }
 
+// The same side in the LITERAL association (feedback_gnn.py:175-184 term by term; oracle: gnn_edge_side): one whole message MLP per
+// edge — four-term first Dense from 0, + b1, tanh, 40 -> 20 Dense over ascending j from 0, + b2 — then the edges' messages summed in
+// ascending check order and divided by their number.  One lane per qubit, weights as scalar operands like side_stream; the edge loop
+// is a real loop (unrolled, the compiler interleaves the edges and spills a hundred registers).  Round 4: 13.4 ms against the MFMA
+// tiles' 14.7 on [[882,24]] x 65 536 (profiles/r4_gnn_literal_stream_ab.txt); with plain v_fmac for the second Dense it was 15.2.
+template <int DV>
+__device__ __forceinline__ void side_stream_literal(scalar_fp rows, scalar_fp b2, const float (&gv)[DV], float X, float Y, float Z,
+                                                    float* __restrict__ feat)
+{
+    // the 40 -> 20 Dense of an edge as ten v_pk_fma_f32 per hidden unit: two consecutive message elements per instruction, their
+    // weights W2[j][2i], W2[j][2i + 1] one SGPR pair (rows are 32 floats, W2 at float 8: 8-byte aligned), the per-lane tanh value
+    // broadcast to both halves — each half an IEEE fma in the oracle's order (ascending j from 0)
+#pragma unroll 1
+    for (int e = 0; e < DV; ++e) {
+        float ge = gv[0];
+#pragma unroll
+        for (int k = 1; k < DV; ++k) ge = e == k ? gv[k] : ge;
+        f2 m[MSG / 2];
+#pragma unroll
+        for (int i = 0; i < MSG / 2; ++i) m[i] = bc2(0.0f);
+#pragma unroll FGNN_GNNS_LIT_UNROLL
+        for (int j = 0; j < HID; ++j) {
+            scalar_fp r = rows + j * SROW;
+            scalar_f2p w2 = (scalar_f2p)(r + 8);
+            float a = 0.0f;
+            a = FG_FMA(ge, r[0], a);
+            a = FG_FMA(X, r[1], a);
+            a = FG_FMA(Y, r[2], a);
+            a = FG_FMA(Z, r[3], a);
+            const f2 h = bc_lo(fg_tanh(a + r[4]));
+#pragma unroll
+            for (int i = 0; i < MSG / 2; ++i) m[i] = pk_fma(h, w2[i], m[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < MSG / 2; ++i) {
+            const float m0 = m[i].x + b2[2 * i], m1 = m[i].y + b2[2 * i + 1];
+            feat[2 * i] = (e == 0) ? m0 : feat[2 * i] + m0;
+            feat[2 * i + 1] = (e == 0) ? m1 : feat[2 * i + 1] + m1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MSG; ++i) feat[i] = DV == 3 ? fg_div3(feat[i]) : feat[i] / (float)DV;
+}
+
 struct EmbRow {
     float we[2 * MSG + 3], be, wo[3];
 };
@@ -446,8 +497,9 @@ __device__ __forceinline__ void emb_unit(const EmbRow& r, const float (&feat)[2 
     for (int i = 0; i < 3; ++i) o[i] = FG_FMA(h, r.wo[i], o[i]);
 }
 
-template <int DV>
-__global__ void __launch_bounds__(1024) FGNN_GNNS_OCC gnn_stream_kernel(GraphDev g, WeightsDev w, GnnArgs a)
+template <int DV, bool LITERAL = false>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LITERAL ? FGNN_GNNS_LIT_WAVES : FGNN_GNNS_WAVES, LITERAL ? FGNN_GNNS_LIT_WAVES : FGNN_GNNS_WAVES)))
+gnn_stream_kernel(GraphDev g, WeightsDev w, GnnArgs a)
 {
     extern __shared__ float lds[];
     const int slot_b = blockIdx.x;
@@ -475,12 +527,14 @@ __global__ void __launch_bounds__(1024) FGNN_GNNS_OCC gnn_stream_kernel(GraphDev
         // unit loop instead of inside it, where the wait would also cover the loop's weight loads
 #pragma unroll
         for (int k = 0; k < DV; ++k) asm volatile("" : "+v"(gv[k]));
-        side_stream<DV>(mrx, b2x, gv, X, Y, Z, feat);
+        if constexpr (LITERAL) side_stream_literal<DV>(mrx, b2x, gv, X, Y, Z, feat);
+        else side_stream<DV>(mrx, b2x, gv, X, Y, Z, feat);
 #pragma unroll
         for (int k = 0; k < DV; ++k) gv[k] = gcn[g.m_x + g.vchk[g.E_x + v * DV + k]];
 #pragma unroll
         for (int k = 0; k < DV; ++k) asm volatile("" : "+v"(gv[k]));
-        side_stream<DV>(mrz, b2z, gv, X, Y, Z, feat + MSG);
+        if constexpr (LITERAL) side_stream_literal<DV>(mrz, b2z, gv, X, Y, Z, feat + MSG);
+        else side_stream<DV>(mrz, b2z, gv, X, Y, Z, feat + MSG);
         // vn_embed_mlp Dense(40,tanh) on [m_x | m_z | X,Y,Z], then _llr_inv_embed Dense(3)  (:186)
         float o[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll FGNN_GNNS_UNROLL
@@ -842,10 +896,11 @@ int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const flo
     }
     // Below ~4 000 codewords the launch is latency-bound, and there the MFMA-tile kernel, which deals one codeword's tiles to many waves,
     // is up to 3x quicker (18 vs 52 us for <= 64 codewords of [[882,24]]; equal from 256 to 2 048; the streaming kernel wins from 4 096 on:
-    // profiles/r3_gnn_stream_ab.txt) - same bits either way.  Degrees 4 and 5 have no MFMA-tile kernel and always stream.
-    const bool stream_pays = g->gnn_stream == 2 || g->d.dvx != 3 || B >= 4096;
-    if (g->d.dvx == g->d.dvz && g->d.dvx >= 3 && g->d.dvx <= 5 && !g->force_generic && g->gnn_factored && g->gnn_stream && stream_pays) {
-        // degree-regular graph (3, 4 or 5 checks per qubit and side: the GHP, GB and bivariate-bicycle families), factored association:
+    // profiles/r3_gnn_stream_ab.txt; the literal association's streaming kernel from 8 192 on: profiles/r4_gnn_literal_stream_ab.txt) -
+    // same bits either way.  Degrees 4 and 5 have no MFMA-tile kernel and always stream.
+    const bool stream_pays = g->gnn_stream == 2 || g->d.dvx != 3 || B >= (g->gnn_factored ? 4096 : 8192);  // measured crossovers
+    if (g->d.dvx == g->d.dvz && g->d.dvx >= 3 && g->d.dvx <= 5 && !g->force_generic && g->gnn_stream && stream_pays) {
+        // degree-regular graph (3, 4 or 5 checks per qubit and side: the GHP, GB and bivariate-bicycle families), either association:
         // streaming VALU kernel, one codeword per workgroup, one lane per qubit.  The
         // workgroup size minimises idle lanes (882 qubits: 7 passes of 128 threads, 1270: 5 passes of 256; 882 / 896 and 1270 / 1280
         // lanes busy) and, among equals, is the largest up to 256 threads (measured: 128 .. 256 best); few codewords take the widest
@@ -864,7 +919,8 @@ int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const flo
         best_tpc = FGNN_GNNS_TPC;
 #endif
         const size_t lds_s = (size_t)a.lds_per_cw * sizeof(float);
-        auto skern = g->d.dvx == 3 ? gnn_stream_kernel<3> : g->d.dvx == 4 ? gnn_stream_kernel<4> : gnn_stream_kernel<5>;
+        auto skern = g->gnn_factored ? (g->d.dvx == 3 ? gnn_stream_kernel<3> : g->d.dvx == 4 ? gnn_stream_kernel<4> : gnn_stream_kernel<5>)
+                                     : (g->d.dvx == 3 ? gnn_stream_kernel<3, true> : g->d.dvx == 4 ? gnn_stream_kernel<4, true> : gnn_stream_kernel<5, true>);
         hipLaunchKernelGGL(skern, dim3((unsigned)B), dim3(best_tpc), lds_s, static_cast<hipStream_t>(stream), g->d, w->d, a);
         FGNN_HIP_CHECK(hipGetLastError());
         prof.done(FGNN_PROF_TAG_GNN, B);

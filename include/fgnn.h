@@ -115,13 +115,14 @@ int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords
  * decodes the same number of samples (24 M compared at p = 0.06 .. 0.10 on both codes: differences within 1.8 sigma, both signs,
  * profiles/r3j_bp4_shared_lse_ab.txt), paired block-error counts on 40 M samples agree (profiles/r3v_bp4_lse_forms_mcnemar.json) and the
  * 77 published rows land on the same z-scores (max |z| 1.89, profiles/r3k_published_curves_bp4_shared_lse.json).  A caller who needs the
- * reference's operation sequence term by term sets options 4 and 5 to 0 (bench.py: `literal_forms`, 0.83 of the default's rate).  The
+ * reference's operation sequence term by term sets options 4 and 5 to 0 (bench.py: `literal_forms`, 0.85 of the default's rate).  The
  * oracle restates both forms (og_graph_set_vn_shared_lse); the kernels equal it bit for bit in either.
- * FGNN_OPT_GNN_STREAM (default 1): which kernel runs the factored feedback GNN on a graph with 3, 4 or 5 checks per qubit and side — the
- * streaming VALU kernel (one lane per qubit, weights as scalar operands) or the MFMA-tile kernel ((3,3) only; other degrees: the
- * runtime-degree kernel).  0: never the streaming kernel; 1: wherever it is the faster one (from 4 096 codewords per launch on; smaller
- * launches are latency-bound and quicker on the MFMA tiles); 2: always.  The same float operations in the same order: results are
- * bit-identical; the option exists for A/B timing and tests.  No effect on the literal order (MFMA tiles) or on irregular graphs. */
+ * FGNN_OPT_GNN_STREAM (default 1): which kernel runs the feedback GNN (either association) on a graph with 3, 4 or 5 checks per qubit and
+ * side — the streaming VALU kernel (one lane per qubit, weights as scalar operands; the literal association's 40 -> 20 Dense per edge as
+ * v_pk_fma_f32 on scalar weight pairs) or the MFMA-tile kernel ((3,3) only; other degrees: the runtime-degree kernel).  0: never the
+ * streaming kernel; 1: wherever it is the faster one (from 4 096 codewords per launch on in the factored association, from 8 192 in the
+ * literal one; smaller launches are latency-bound and quicker on the MFMA tiles); 2: always.  The same float operations in the same
+ * order: results are bit-identical; the option exists for A/B timing and tests.  No effect on irregular graphs. */
 enum { FGNN_OPT_SATURATION_SHORTCUT = 1, FGNN_OPT_FIXED_POINT_EXIT = 2, FGNN_OPT_HW_TRANSCENDENTALS = 3, FGNN_OPT_GNN_FACTORED = 4,
        FGNN_OPT_BP4_SHARED_LSE = 5, FGNN_OPT_GNN_STREAM = 6 };
 int fgnn_graph_set_option(fgnn_graph* g, int option, int value);

@@ -70,17 +70,16 @@ def test_both_orders_bit_exact_on_mfma_and_valu_kernels(name, wfile, p):
                     gg.force_generic(False)
                 # a compacted round's geometry: few codewords, a codeword's tiles dealt to several wave-quads
                 c = gg.feedback_gnn(gw, *[t[:3].contiguous() for t in args[1:]]).cpu().numpy()
-                if fact:
-                    # a, c ran on the streaming VALU kernel (the default of the factored order on a regular graph): the MFMA-tile
-                    # kernel in the same order must give the same bits
-                    gg.set_gnn_stream(False)
-                    try:
-                        a2 = gg.feedback_gnn(*args).cpu().numpy()
-                        c2 = gg.feedback_gnn(gw, *[t[:3].contiguous() for t in args[1:]]).cpu().numpy()
-                    finally:
-                        gg.set_gnn_stream("always")
-                    assert np.array_equal(ref, a2), f"{tag} factored MFMA kernel: max|d|={np.abs(ref - a2).max()}"
-                    assert np.array_equal(ref[:3], c2), f"{tag} factored MFMA kernel, small launch"
+                # a, c ran on the streaming VALU kernel (both orders have one on a regular graph; _order forces it at every launch
+                # size): the MFMA-tile kernel in the same order must give the same bits
+                gg.set_gnn_stream(False)
+                try:
+                    a2 = gg.feedback_gnn(*args).cpu().numpy()
+                    c2 = gg.feedback_gnn(gw, *[t[:3].contiguous() for t in args[1:]]).cpu().numpy()
+                finally:
+                    gg.set_gnn_stream("always")
+                assert np.array_equal(ref, a2), f"{tag} factored={fact} MFMA kernel: max|d|={np.abs(ref - a2).max()}"
+                assert np.array_equal(ref[:3], c2), f"{tag} factored={fact} MFMA kernel, small launch"
             assert np.array_equal(ref, a), f"{tag} factored={fact} default kernel: max|d|={np.abs(ref - a).max()}"
             assert np.array_equal(ref, b), f"{tag} factored={fact} VALU kernel: max|d|={np.abs(ref - b).max()}"
             assert np.array_equal(ref[:3], c), f"{tag} factored={fact} small launch"
@@ -107,20 +106,21 @@ def test_streaming_kernel_on_the_other_regular_degrees(name, B):
     llr = o["llr"].copy()
     llr[0] = 0.0                       # all-zero marginals
     llr[-1] = np.float32(53.9496498)   # saturated
-    with _order(name, True) as (og_, gg_):
-        ref = og_.feedback_gnn(wr, llr, o["z_logit"], o["x_logit"], sx, sz)
-        gw = GnnWeights(wr, gg_.device)
-        args = (gw, to_gpu(llr), to_gpu(o["z_logit"]), to_gpu(o["x_logit"]), to_gpu(sx), to_gpu(sz))
-        a = gg_.feedback_gnn(*args).cpu().numpy()
-        gg_.force_generic(True)
-        try:
-            b = gg_.feedback_gnn(*args).cpu().numpy()
-        finally:
-            gg_.force_generic(False)
-        one = gg_.feedback_gnn(gw, *[t[B - 1:].contiguous() for t in args[1:]]).cpu().numpy()
-    assert np.array_equal(ref, a), np.abs(ref - a).max()
-    assert np.array_equal(ref, b) and np.array_equal(ref[B - 1:], one)
-    assert np.isfinite(ref).all() and np.abs(ref).max() > 1.0
+    for fact in (True, False):  # both associations have a streaming kernel per degree
+        with _order(name, fact) as (og_, gg_):
+            ref = og_.feedback_gnn(wr, llr, o["z_logit"], o["x_logit"], sx, sz)
+            gw = GnnWeights(wr, gg_.device)
+            args = (gw, to_gpu(llr), to_gpu(o["z_logit"]), to_gpu(o["x_logit"]), to_gpu(sx), to_gpu(sz))
+            a = gg_.feedback_gnn(*args).cpu().numpy()
+            gg_.force_generic(True)
+            try:
+                b = gg_.feedback_gnn(*args).cpu().numpy()
+            finally:
+                gg_.force_generic(False)
+            one = gg_.feedback_gnn(gw, *[t[B - 1:].contiguous() for t in args[1:]]).cpu().numpy()
+        assert np.array_equal(ref, a), (fact, np.abs(ref - a).max())
+        assert np.array_equal(ref, b) and np.array_equal(ref[B - 1:], one), fact
+        assert np.isfinite(ref).all() and np.abs(ref).max() > 1.0
 
 
 def test_both_orders_within_tolerance_of_the_numpy_restatement():
@@ -148,28 +148,30 @@ def test_sandwich_bit_exact_in_both_orders_and_same_corrections(name, wfile, ite
 
 
 def test_kernel_choice_by_launch_size_gives_the_same_bits():
-    """FGNN_OPT_GNN_STREAM = 1 (the default): MFMA tiles below 4 096 codewords per launch, the streaming kernel from there on — at both
-    sides of the switch the output equals that of either kernel forced."""
+    """FGNN_OPT_GNN_STREAM = 1 (the default): MFMA tiles below 4 096 codewords per launch (8 192 in the literal association), the
+    streaming kernel from there on — at both sides of the switch the output equals that of either kernel forced."""
+    import torch
     from feedback_gnn_amd.graph import GnnWeights
     from feedback_gnn_amd.weights_io import read_weight_list
     gg = gpu_graph("ghp882")
-    B = 4096
-    ex, ez = gg.pauli_noise(SEED, 0.10, 0, B)
+    ex, ez = gg.pauli_noise(SEED, 0.10, 0, 8192)
     sx, sz = gg.syndrome(ex, ez)
     o = gg.bp4_decode(sx, sz, 8, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
     gw = GnnWeights(read_weight_list(WEIGHTS_882), gg.device)
-    outs = {}
     try:
-        for mode in (False, True, "always"):
-            gg.set_gnn_stream(mode)
-            assert gg.gnn_stream == mode
-            outs[mode, B] = gg.feedback_gnn(gw, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
-            outs[mode, B - 1] = gg.feedback_gnn(gw, *[t[:B - 1].contiguous() for t in (o["llr"], o["z_logit"], o["x_logit"], sx, sz)])
+        for fact, B in ((True, 4096), (False, 8192)):
+            gg.set_gnn_factored(fact)
+            outs = {}
+            for mode in (False, True, "always"):
+                gg.set_gnn_stream(mode)
+                assert gg.gnn_stream == mode
+                for n in (B, B - 1):
+                    outs[mode, n] = gg.feedback_gnn(gw, *[t[:n].contiguous() for t in (o["llr"], o["z_logit"], o["x_logit"], sx, sz)])
+            for n in (B, B - 1):
+                assert torch.equal(outs[False, n], outs[True, n]) and torch.equal(outs[True, n], outs["always", n]), (fact, n)
     finally:
         gg.set_gnn_stream(True)
-    import torch
-    for n in (B, B - 1):
-        assert torch.equal(outs[False, n], outs[True, n]) and torch.equal(outs[True, n], outs["always", n])
+        gg.set_gnn_factored(True)
     with pytest.raises(Exception, match="0, 1 or 2"):
         from feedback_gnn_amd import _lib
         _lib.check(_lib.lib().fgnn_graph_set_option(gg.handle, 6, 3))
