@@ -360,7 +360,12 @@ __global__ void __launch_bounds__(1024) gnn_kernel(GraphDev g, WeightsDev w, Gnn
 // Per-unit weight rows are packed at upload: msg_rows[side][j][32] = W1[0..3][j], b1[j], 0,0,0, W2[j][0..19], 0,0,0,0;
 // emb_rows[j][48] = We[0..42][j], be[j], Wout[j][0..2], 0.
 // ---------------------------------------------------------------------------------------------
-constexpr int SROW = 32, EROW = 48;
+#ifndef FGNN_GNNS_EMB_U
+#define FGNN_GNNS_EMB_U 4  // hidden units of the embed MLP per block of the packed form (EMB_U / 2 independent packed chains)
+#endif
+constexpr int EMB_U = FGNN_GNNS_EMB_U;
+constexpr int SROW = 32, EROW = 48, EQUAD = ((43 + 1 + 3) * EMB_U + 31) / 32 * 32;  // 192 floats for blocks of four
+static_assert(HID % EMB_U == 0 && EMB_U % 2 == 0, "the embed MLP walks its hidden units in blocks");
 // measured (profiles/r3_gnn_stream_ab.txt): a register budget of 6 or 7 waves per SIMD, one hidden unit per loop trip (its DV tanh chains
 // interleave) and the LDS reads of the check features waited for BEFORE the unit loop are the best of waves 6 / 7 / 8 x unroll 1 / 2
 // x software-pipelined or not; requesting the next unit's row ahead of time (hand-placed s_load / s_waitcnt) was slower, because the
@@ -370,6 +375,15 @@ constexpr int SROW = 32, EROW = 48;
 #endif
 #ifndef FGNN_GNNS_WAVES
 #define FGNN_GNNS_WAVES 7
+#endif
+#ifndef FGNN_GNNS_EMBPK_FACT
+#define FGNN_GNNS_EMBPK_FACT 1
+#endif
+#ifndef FGNN_GNNS_EMBPK_LIT
+#define FGNN_GNNS_EMBPK_LIT 1
+#endif
+#ifndef FGNN_GNNS_EMB_KG
+#define FGNN_GNNS_EMB_KG 4  // embed-MLP weight rows (of four floats) per scalar-load group
 #endif
 #ifndef FGNN_GNNS_LIT_UNROLL
 #define FGNN_GNNS_LIT_UNROLL 1  // measured: 13.4 ms at 1, 13.8 at 2, 13.7 at 4 ([[882,24]] x 65 536)
@@ -430,7 +444,7 @@ __device__ __forceinline__ void side_stream(scalar_fp rows, scalar_fp b2, const 
 // The same side in the LITERAL association (feedback_gnn.py:175-184 term by term; oracle: gnn_edge_side): one whole message MLP per
 // edge — four-term first Dense from 0, + b1, tanh, 40 -> 20 Dense over ascending j from 0, + b2 — then the edges' messages summed in
 // ascending check order and divided by their number.  One lane per qubit, weights as scalar operands like side_stream; the edge loop
-// is a real loop (unrolled, the compiler interleaves the edges and spills a hundred registers).  Round 4: 13.4 ms against the MFMA
+// is a real loop (unrolled, the compiler interleaves the edges and spills a hundred registers).  Round 4: 12.9 ms against the MFMA
 // tiles' 14.7 on [[882,24]] x 65 536 (profiles/r4_gnn_literal_stream_ab.txt); with plain v_fmac for the second Dense it was 15.2.
 template <int DV>
 __device__ __forceinline__ void side_stream_literal(scalar_fp rows, scalar_fp b2, const float (&gv)[DV], float X, float Y, float Z,
@@ -484,7 +498,7 @@ __device__ __forceinline__ EmbRow load_emb_row(scalar_fp r)
     for (int i = 0; i < 3; ++i) m.wo[i] = r[44 + i];
     return m;
 }
-__device__ __forceinline__ void emb_unit(const EmbRow& r, const float (&feat)[2 * MSG], float X, float Y, float Z, float (&o)[3])
+__device__ __forceinline__ void emb_unit(const EmbRow& r, const float* __restrict__ feat, float X, float Y, float Z, float (&o)[3])
 {
     float acc = 0.0f;
 #pragma unroll
@@ -497,7 +511,36 @@ __device__ __forceinline__ void emb_unit(const EmbRow& r, const float (&feat)[2 
     for (int i = 0; i < 3; ++i) o[i] = FG_FMA(h, r.wo[i], o[i]);
 }
 
-template <int DV, bool LITERAL = false>
+// Four hidden units of the embed MLP at once (emb_quads): the 43-term first Dense as v_pk_fma_f32 — two units per instruction, their
+// weights We[k][j], We[k][j + 1] one SGPR pair, the per-lane input broadcast to both halves by op_sel; two independent chains.  Each half
+// is the IEEE fma of emb_unit in the same order (ascending k from 0), so the bits are those of the scalar-operand form.  Measured
+// (round 4, [[882,24]] x 65 536): factored kernel 9.25 -> 9.08 ms, literal 13.48 -> 12.94; blocks of 2, 4 or 8 units and 2 .. 8 weight rows
+// per scalar-load group all within 1 % of each other; the SAME packing of the factored association's 40 -> 20 Dense gains nothing
+// (9.06 / 9.08 ms): that kernel is bound by the tanh chains' issue slots, and a packed fma costs two.  The inputs are passed through
+// an empty asm IN PLACE first: loop-invariant pairs would otherwise have their {x, x} broadcasts hoisted out of the caller's loop as 43
+// more live register pairs.
+__device__ __forceinline__ void emb_quad(const float* quad, f2 (&fx)[2 * MSG / 2 + 2], float (&o)[3])
+{
+#pragma unroll
+    for (int q = 0; q < 2 * MSG / 2 + 2; ++q) asm volatile("" : "+v"(fx[q]));
+    f2 acc[EMB_U / 2];
+#pragma unroll
+    for (int jp = 0; jp < EMB_U / 2; ++jp) acc[jp] = bc2(0.0f);
+    dense_pk<2 * MSG + 3, EMB_U / 2, FGNN_GNNS_EMB_KG, false>(fx, quad, EMB_U, acc);
+    scalar_fp r = as_scalar(quad);
+    float h[EMB_U];
+#pragma unroll
+    for (int jp = 0; jp < EMB_U / 2; ++jp) {
+        h[2 * jp] = fg_tanh(acc[jp].x + r[43 * EMB_U + 2 * jp]);
+        h[2 * jp + 1] = fg_tanh(acc[jp].y + r[43 * EMB_U + 2 * jp + 1]);
+    }
+#pragma unroll
+    for (int u = 0; u < EMB_U; ++u)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o[i] = FG_FMA(h[u], r[44 * EMB_U + 3 * u + i], o[i]);
+}
+
+template <int DV, bool LITERAL = false, bool EMBPK = false>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LITERAL ? FGNN_GNNS_LIT_WAVES : FGNN_GNNS_WAVES, LITERAL ? FGNN_GNNS_LIT_WAVES : FGNN_GNNS_WAVES)))
 gnn_stream_kernel(GraphDev g, WeightsDev w, GnnArgs a)
 {
@@ -519,7 +562,8 @@ gnn_stream_kernel(GraphDev g, WeightsDev w, GnnArgs a)
     scalar_fp b2x = as_scalar(w.b2[0]), b2z = as_scalar(w.b2[1]), bo = as_scalar(w.bout);
     for (int v = threadIdx.x; v < n; v += blockDim.x) {
         const float X = in[v], Y = in[n + v], Z = in[2 * n + v];
-        float feat[2 * MSG];
+        f2 fx[MSG + 2];  // [m_x | m_z | X, Y | Z, -] as pairs of consecutive elements (the packed embed MLP reads them as such)
+        float* feat = reinterpret_cast<float*>(fx);
         float gv[DV];
 #pragma unroll
         for (int k = 0; k < DV; ++k) gv[k] = gcn[g.vchk[v * DV + k]];
@@ -537,8 +581,15 @@ gnn_stream_kernel(GraphDev g, WeightsDev w, GnnArgs a)
         else side_stream<DV>(mrz, b2z, gv, X, Y, Z, feat + MSG);
         // vn_embed_mlp Dense(40,tanh) on [m_x | m_z | X,Y,Z], then _llr_inv_embed Dense(3)  (:186)
         float o[3] = {0.0f, 0.0f, 0.0f};
+        if constexpr (EMBPK) {
+            fx[MSG] = f2{X, Y};
+            fx[MSG + 1] = f2{Z, 0.0f};
+#pragma unroll 1
+            for (int q = 0; q < HID / EMB_U; ++q) emb_quad(w.emb_quads + q * EQUAD, fx, o);
+        } else {
 #pragma unroll FGNN_GNNS_UNROLL
-        for (int j = 0; j < HID; ++j) emb_unit(load_emb_row(er + j * EROW), feat, X, Y, Z, o);
+            for (int j = 0; j < HID; ++j) emb_unit(load_emb_row(er + j * EROW), feat, X, Y, Z, o);
+        }
         out[v] = o[0] + bo[0];
         out[n + v] = o[1] + bo[1];
         out[2 * n + v] = o[2] + bo[2];
@@ -715,6 +766,17 @@ extern "C" int fgnn_weights_create(const float* const host_arrays[12], int devic
         r[43] = host_arrays[11][j];
         for (int i = 0; i < 3; ++i) r[44 + i] = host_arrays[0][j * 3 + i];
     }
+    while (h.size() % 32) h.push_back(0.0f);
+    const size_t off_eq = push((size_t)(HID / EMB_U) * EQUAD);
+    for (int q = 0; q < HID / EMB_U; ++q) {
+        float* r = &h[off_eq + (size_t)q * EQUAD];
+        for (int k = 0; k < 43; ++k)
+            for (int u = 0; u < EMB_U; ++u) r[EMB_U * k + u] = host_arrays[10][k * HID + EMB_U * q + u];
+        for (int u = 0; u < EMB_U; ++u) {
+            r[43 * EMB_U + u] = host_arrays[11][EMB_U * q + u];
+            for (int i = 0; i < 3; ++i) r[44 * EMB_U + 3 * u + i] = host_arrays[0][(EMB_U * q + u) * 3 + i];
+        }
+    }
     // per-lane MFMA operand tables (see the T_* enum above)
     const size_t off_tab = push((size_t)T_COUNT * 64);
     {
@@ -778,6 +840,7 @@ extern "C" int fgnn_weights_create(const float* const host_arrays[12], int devic
     w->d.msg_rows[0] = base + off_mr[0];
     w->d.msg_rows[1] = base + off_mr[1];
     w->d.emb_rows = base + off_er;
+    w->d.emb_quads = base + off_eq;
     *out = w;
     return FGNN_OK;
 }
@@ -896,9 +959,9 @@ int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const flo
     }
     // Below ~4 000 codewords the launch is latency-bound, and there the MFMA-tile kernel, which deals one codeword's tiles to many waves,
     // is up to 3x quicker (18 vs 52 us for <= 64 codewords of [[882,24]]; equal from 256 to 2 048; the streaming kernel wins from 4 096 on:
-    // profiles/r3_gnn_stream_ab.txt; the literal association's streaming kernel from 8 192 on: profiles/r4_gnn_literal_stream_ab.txt) -
+    // profiles/r3_gnn_stream_ab.txt; the literal association's streaming kernel likewise: profiles/r4_gnn_literal_stream_ab.txt) -
     // same bits either way.  Degrees 4 and 5 have no MFMA-tile kernel and always stream.
-    const bool stream_pays = g->gnn_stream == 2 || g->d.dvx != 3 || B >= (g->gnn_factored ? 4096 : 8192);  // measured crossovers
+    const bool stream_pays = g->gnn_stream == 2 || g->d.dvx != 3 || B >= 4096;
     if (g->d.dvx == g->d.dvz && g->d.dvx >= 3 && g->d.dvx <= 5 && !g->force_generic && g->gnn_stream && stream_pays) {
         // degree-regular graph (3, 4 or 5 checks per qubit and side: the GHP, GB and bivariate-bicycle families), either association:
         // streaming VALU kernel, one codeword per workgroup, one lane per qubit.  The
@@ -919,8 +982,9 @@ int fgnn_feedback_gnn_impl(const fgnn_graph* g, const fgnn_weights* w, const flo
         best_tpc = FGNN_GNNS_TPC;
 #endif
         const size_t lds_s = (size_t)a.lds_per_cw * sizeof(float);
-        auto skern = g->gnn_factored ? (g->d.dvx == 3 ? gnn_stream_kernel<3> : g->d.dvx == 4 ? gnn_stream_kernel<4> : gnn_stream_kernel<5>)
-                                     : (g->d.dvx == 3 ? gnn_stream_kernel<3, true> : g->d.dvx == 4 ? gnn_stream_kernel<4, true> : gnn_stream_kernel<5, true>);
+        constexpr bool PF = FGNN_GNNS_EMBPK_FACT != 0, PL = FGNN_GNNS_EMBPK_LIT != 0;
+        auto skern = g->gnn_factored ? (g->d.dvx == 3 ? gnn_stream_kernel<3, false, PF> : g->d.dvx == 4 ? gnn_stream_kernel<4, false, PF> : gnn_stream_kernel<5, false, PF>)
+                                     : (g->d.dvx == 3 ? gnn_stream_kernel<3, true, PL> : g->d.dvx == 4 ? gnn_stream_kernel<4, true, PL> : gnn_stream_kernel<5, true, PL>);
         hipLaunchKernelGGL(skern, dim3((unsigned)B), dim3(best_tpc), lds_s, static_cast<hipStream_t>(stream), g->d, w->d, a);
         FGNN_HIP_CHECK(hipGetLastError());
         prof.done(FGNN_PROF_TAG_GNN, B);

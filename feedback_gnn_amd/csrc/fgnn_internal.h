@@ -79,6 +79,7 @@ struct WeightsDev {
     const float* lane_tab;  // [132][64] per-lane MFMA operand / bias tables (fgnn_gnn.hip, mfma path)
     const float* msg_rows[2];  // [40][32] per hidden unit: W1[0..3][j], b1[j], 0,0,0, W2[j][0..19], 0 x 4 (gnn_stream_kernel)
     const float* emb_rows;     // [40][48] per hidden unit: We[0..42][j], be[j], Wout[j][0..2], 0
+    const float* emb_quads;    // [10][192] per four hidden units j0..j0+3: We[k][j0..j0+3] for k = 0..42, be[j0..j0+3], Wout[j0+u][0..2] for u = 0..3, 0 x 4
 };
 
 // Runtime-shaped feedback GNN (fgnn_weights_create_general): Dense layers in execution order

@@ -23,7 +23,8 @@ __device__ __forceinline__ f2 bc2(float x) { return f2{x, x}; }
 // anything across the group boundaries (left alone it hoists every s_load of a layer to the top and spills hundreds of SGPRs).  The
 // input pairs pass through an empty asm at the top: a loop-invariant input would otherwise have its {x, x} broadcasts hoisted out of
 // the caller's block loop as twice as many live registers.
-template <int K, int JP, int KG>
+// (LAUNDER = false: the caller has passed its pairs through such an asm itself, in place — no copies at all.)
+template <int K, int JP, int KG, bool LAUNDER = true>
 __device__ __forceinline__ void dense_pk(const f2 (&in2)[(K + 1) / 2], const float* w, int stride, f2 (&acc)[JP])
 {
     constexpr int NG = (K + KG - 1) / KG, KP = (K + 1) / 2;
@@ -31,7 +32,7 @@ __device__ __forceinline__ void dense_pk(const f2 (&in2)[(K + 1) / 2], const flo
 #pragma unroll
     for (int q = 0; q < KP; ++q) {
         x[q] = in2[q];
-        asm volatile("" : "+v"(x[q]));
+        if constexpr (LAUNDER) asm volatile("" : "+v"(x[q]));
     }
     f2 buf[2][KG][JP];
 #pragma unroll

@@ -172,7 +172,7 @@ class TannerGraph:
 
     def set_gnn_stream(self, on=True):
         """Feedback GNN of a regular graph on the streaming VALU kernel (FGNN_OPT_GNN_STREAM): True (default) = wherever it is the
-        faster kernel (launches of 4 096 codewords or more; 8 192 in the literal association), "always" = every launch, False = never
+        faster kernel (launches of 4 096 codewords or more), "always" = every launch, False = never
         (MFMA-tile kernel).  The same float operations in the same order: bit-identical results."""
         value = 2 if on == "always" else int(bool(on))
         check(_lib.lib().fgnn_graph_set_option(self.handle, 6, value))

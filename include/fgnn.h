@@ -120,8 +120,8 @@ int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords
  * FGNN_OPT_GNN_STREAM (default 1): which kernel runs the feedback GNN (either association) on a graph with 3, 4 or 5 checks per qubit and
  * side — the streaming VALU kernel (one lane per qubit, weights as scalar operands; the literal association's 40 -> 20 Dense per edge as
  * v_pk_fma_f32 on scalar weight pairs) or the MFMA-tile kernel ((3,3) only; other degrees: the runtime-degree kernel).  0: never the
- * streaming kernel; 1: wherever it is the faster one (from 4 096 codewords per launch on in the factored association, from 8 192 in the
- * literal one; smaller launches are latency-bound and quicker on the MFMA tiles); 2: always.  The same float operations in the same
+ * streaming kernel; 1: wherever it is the faster one (from 4 096 codewords per launch on; smaller launches are latency-bound and
+ * quicker on the MFMA tiles); 2: always.  The same float operations in the same
  * order: results are bit-identical; the option exists for A/B timing and tests.  No effect on irregular graphs. */
 enum { FGNN_OPT_SATURATION_SHORTCUT = 1, FGNN_OPT_FIXED_POINT_EXIT = 2, FGNN_OPT_HW_TRANSCENDENTALS = 3, FGNN_OPT_GNN_FACTORED = 4,
        FGNN_OPT_BP4_SHARED_LSE = 5, FGNN_OPT_GNN_STREAM = 6 };

@@ -148,18 +148,18 @@ def test_sandwich_bit_exact_in_both_orders_and_same_corrections(name, wfile, ite
 
 
 def test_kernel_choice_by_launch_size_gives_the_same_bits():
-    """FGNN_OPT_GNN_STREAM = 1 (the default): MFMA tiles below 4 096 codewords per launch (8 192 in the literal association), the
+    """FGNN_OPT_GNN_STREAM = 1 (the default): MFMA tiles below 4 096 codewords per launch (either association), the
     streaming kernel from there on — at both sides of the switch the output equals that of either kernel forced."""
     import torch
     from feedback_gnn_amd.graph import GnnWeights
     from feedback_gnn_amd.weights_io import read_weight_list
     gg = gpu_graph("ghp882")
-    ex, ez = gg.pauli_noise(SEED, 0.10, 0, 8192)
+    ex, ez = gg.pauli_noise(SEED, 0.10, 0, 4096)
     sx, sz = gg.syndrome(ex, ez)
     o = gg.bp4_decode(sx, sz, 8, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
     gw = GnnWeights(read_weight_list(WEIGHTS_882), gg.device)
     try:
-        for fact, B in ((True, 4096), (False, 8192)):
+        for fact, B in ((True, 4096), (False, 4096)):
             gg.set_gnn_factored(fact)
             outs = {}
             for mode in (False, True, "always"):

@@ -39,7 +39,20 @@ def pick(rows, prefix, accept=lambda name: True):
     """The (kernel, workgroup/duration bucket) row with the longest launches among the kernels whose name starts with `prefix`."""
     cands = [(k, v) for k, v in rows.items() if k[0].startswith(prefix) and "FETCH_SIZE" in v and accept(k[0])]
     cands.sort(key=lambda kv: kv[1]["FETCH_SIZE"][1], reverse=True)
-    return cands[0] if cands else None
+    if not cands:
+        return None
+    (name, wg), v = cands[0]
+    # pmc_summary.py buckets launches by duration (wg=<threads>/b<log2 bucket>): a launch near a bucket boundary (the 0.15 ms launch of
+    # c1) may land in the neighbouring bucket in another counter's pass — take a counter this row lacks from the same kernel and
+    # workgroup size in the bucket whose launches took the closest time
+    v = dict(v)
+    threads = wg.split("/")[0]
+    for (n2, wg2), v2 in rows.items():
+        if n2 == name and wg2 != wg and wg2.split("/")[0] == threads:
+            for ctr, (val, ms) in v2.items():
+                if ctr not in v and abs(ms - v["FETCH_SIZE"][1]) <= 0.1 * v["FETCH_SIZE"][1]:
+                    v[ctr] = (val, ms)
+    return (name, wg), v
 
 
 def entry(kind, name, v):
