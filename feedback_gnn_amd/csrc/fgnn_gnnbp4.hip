@@ -1397,10 +1397,14 @@ extern "C" int fgnn_gnnbp4_decode(const fgnn_graph* g, const fgnn_gnnbp4_weights
         if (lds_s > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "code too large for the GNN_BP4 streaming kernel");
         auto kern = g->gnn_factored ? gnn_bp4_stream_kernel<3, 6, true> : gnn_bp4_stream_kernel<3, 6, false>;
         GnnBp4Dev wd = w->d;
+#ifdef FGNN_PROBES  // timing probe, never in the shipped library (make EXTRA=-DFGNN_PROBES; results wrong by construction: every MLP reads ONE 10 KB weight set)
         static const bool alias_probe = getenv("FGNN_PROBE_ALIAS_WEIGHTS") != nullptr;
-        if (alias_probe) {  // timing probe (tools/ab_gnnbp4_stream.py), results wrong by construction: every MLP reads ONE 10 KB weight set
+        if (alias_probe) {
             for (MlpDev* q : {&wd.cn_msg[0], &wd.cn_msg[1], &wd.cn_embed[0], &wd.cn_embed[1], &wd.vn_msg[1], &wd.vn_embed}) *q = wd.vn_msg[0];
         }
+#endif
+        if (lds_s > 48 * 1024)
+            FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
         hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_s, static_cast<hipStream_t>(stream), g->d, wd, a);
         FGNN_HIP_CHECK(hipGetLastError());
         prof.done(FGNN_PROF_TAG_GNNBP4, B);

@@ -173,7 +173,9 @@ class TannerGraph:
     def set_gnn_stream(self, on=True):
         """Feedback GNN of a regular graph on the streaming VALU kernel (FGNN_OPT_GNN_STREAM): True (default) = wherever it is the
         faster kernel (launches of 4 096 codewords or more), "always" = every launch, False = never
-        (MFMA-tile kernel).  The same float operations in the same order: bit-identical results."""
+        (MFMA-tile kernel).  The same float operations in the same order: bit-identical results.  "always" also moves `gnn_bp4_decode`
+        on a (3,3,6)-regular graph to its streaming kernel, which is bit-identical and ~35 % SLOWER than its MFMA tiles (the tested
+        second implementation, include/fgnn.h option 6); True / False leave GNN_BP4 on the MFMA tiles."""
         value = 2 if on == "always" else int(bool(on))
         check(_lib.lib().fgnn_graph_set_option(self.handle, 6, value))
         self.gnn_stream = "always" if value == 2 else bool(value)

@@ -144,6 +144,10 @@ def sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=False, num
     fast = bool(device_counters) and hasattr(mc_fun, "mc_step") and hasattr(mc_fun, "rewind")
     fuse = int(fuse_samples) // max(int(batch_size), 1) if (fast and hasattr(mc_fun, "mc_steps")) else 0
     max_it = int(max_mc_iter)
+    # A model that issues `mc_step` on side streams (streams > 1) adds to the shared counters from those streams: every snapshot below
+    # is ordered behind them first, or it could miss a batch or tear a counter triple.  (A device-side wait; the per-batch snapshots
+    # the stopping rule needs serialise the batches anyway — the fused `mc_steps` launch is what keeps the chip full here.)
+    join = getattr(mc_fun, "join", None) if fast else None
 
     def row(i, st):
         fl = flag_errors[i] / max(nb_blocks[i], 1)
@@ -191,6 +195,8 @@ def sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=False, num
                     probe = mc_fun.mc_step(batch_size, ps[i], None)  # allocates the device counters on the model's device
                     counts = probe
                     ring = torch.zeros((int(max_deferred), 3), dtype=torch.int64, device=counts.device)
+                    if join is not None:
+                        join()
                     ring[0].copy_(counts)
                     j += 1
                 elif fuse > 1 and k - j > 1:
@@ -199,9 +205,13 @@ def sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=False, num
                     j += kk
                 else:
                     mc_fun.mc_step(batch_size, ps[i], counts)
+                    if join is not None:
+                        join()
                     ring[j].copy_(counts)
                     j += 1
             it += k
+            if join is not None:
+                join()
             snap = ring[:k].clone()
             if dist:
                 snap = allreduce_counts(snap)

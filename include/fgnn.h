@@ -122,7 +122,11 @@ int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords
  * v_pk_fma_f32 on scalar weight pairs) or the MFMA-tile kernel ((3,3) only; other degrees: the runtime-degree kernel).  0: never the
  * streaming kernel; 1: wherever it is the faster one (from 4 096 codewords per launch on; smaller launches are latency-bound and
  * quicker on the MFMA tiles); 2: always.  The same float operations in the same
- * order: results are bit-identical; the option exists for A/B timing and tests.  No effect on irregular graphs. */
+ * order: results are bit-identical; the option exists for A/B timing and tests.  No effect on irregular graphs.
+ * Value 2 ALSO moves fgnn_gnnbp4_decode on a (3,3,6)-regular graph from its MFMA-tile kernel to its streaming packed-FMA kernel — the
+ * tested second implementation of the same float operations, bit-identical and SLOWER (180 ms against 134 ms per 16 384 x 10
+ * iterations of [[1270,28]], profiles/r4_gnnbp4_stream_ab.txt); values 0 and 1 leave GNN_BP4 on the MFMA tiles.  A caller who wants
+ * "always" for the feedback GNN and times GNN_BP4 on the same graph handle should set the option back to 1 around GNN_BP4 calls. */
 enum { FGNN_OPT_SATURATION_SHORTCUT = 1, FGNN_OPT_FIXED_POINT_EXIT = 2, FGNN_OPT_HW_TRANSCENDENTALS = 3, FGNN_OPT_GNN_FACTORED = 4,
        FGNN_OPT_BP4_SHARED_LSE = 5, FGNN_OPT_GNN_STREAM = 6 };
 int fgnn_graph_set_option(fgnn_graph* g, int option, int value);

@@ -30,6 +30,7 @@
  *
  * Build: gcc -O2 -ffp-contract=off -mfma -fopenmp -shared -fPIC (oracle/Makefile).
  */
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1404,22 +1405,93 @@ int og_osd0(const og_graph* g, int side, int rank, const int32_t* pivot_rows, co
     return 0;
 }
 
-/* elementwise wrappers so tests can probe the shared math from Python */
+/* elementwise wrappers so tests can probe the shared math from Python.  Function ids (tests/math_bits_exhaustive.hip uses the same
+ * numbering on the device): 0 exp, 1 log, 2 log1p, 3 softplus, 4 phi, 5 tanh, 6 atanh, 7 phi_gnn, 8 lse2_corr(x, 0), 9 sigmoid,
+ * 10 div3, 11 rcp_unit, 12 div_atanh, 13 lse2(x, 1) */
+static inline float og_math_fn(int fn, float v)
+{
+    switch (fn) {
+    case 0: return fg_exp(v);
+    case 1: return fg_log(v);
+    case 2: return fg_log1p(v);
+    case 3: return fg_softplus(v);
+    case 4: return fg_phi(v);
+    case 5: return fg_tanh(v);
+    case 6: return fg_atanh(v);
+    case 7: return fg_phi_gnn(v);
+    case 8: return fg_lse2_corr(v, 0.0f);
+    case 9: return fg_sigmoid(v);
+    case 10: return fg_div3(v);
+    case 11: return fg_rcp_unit(v);
+    case 12: return fg_div_atanh(v);
+    case 13: return fg_lse2(v, 1.0f);
+    default: return 0.0f;
+    }
+}
+
 void og_math_apply(int fn, const float* x, float* y, long nelem)
 {
-    for (long i = 0; i < nelem; ++i) {
-        float v = x[i];
-        switch (fn) {
-        case 0: y[i] = fg_exp(v); break;
-        case 1: y[i] = fg_log(v); break;
-        case 2: y[i] = fg_log1p(v); break;
-        case 3: y[i] = fg_softplus(v); break;
-        case 4: y[i] = fg_phi(v); break;
-        case 5: y[i] = fg_tanh(v); break;
-        case 6: y[i] = fg_atanh(v); break;
-        default: y[i] = 0.0f;
+    for (long i = 0; i < nelem; ++i) y[i] = og_math_fn(fn, x[i]);
+}
+
+/* double-precision libm value of the function an id restates (what `max_ulp` below measures against); NAN = no reference */
+static double og_math_ref(int fn, double x)
+{
+    switch (fn) {
+    case 0: return exp(x);
+    case 1: return log(x);
+    case 2: return log1p(x);
+    case 3: return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x));
+    case 5: return tanh(x);
+    case 6: return atanh(x);
+    case 8: return log1p(exp(-(fabs(x) < 20.0 ? fabs(x) : 20.0)));
+    case 9: return 1.0 / (1.0 + exp(-x));
+    case 10: return x / 3.0;
+    case 11: return 1.0 / x;
+    default: return NAN;
+    }
+}
+
+/* Exhaustive probe of one function over the float32 bit patterns lo..hi (inclusive): the range is cut into windows of
+ * 2^chunk_log2 consecutive bit patterns (aligned to that size), and for every window out[2k] = sum of the result bits,
+ * out[2k+1] = sum of result bits * (input bits | 1), both mod 2^64 (order-free, so the device can accumulate them with atomics:
+ * tests/math_bits_exhaustive.hip forms the same sums from the hipcc build of the same header).  When max_ulp != NULL it also returns
+ * the largest error against double-precision libm in units of the float32 ulp of the exact value, and where it occurs. */
+void og_math_checksums(int fn, uint32_t lo, uint32_t hi, int chunk_log2, uint64_t* out, double* max_ulp, uint32_t* argmax)
+{
+    const int64_t k0 = (int64_t)(lo >> chunk_log2), k1 = (int64_t)(hi >> chunk_log2);
+    double worst = -1.0;
+    uint32_t worst_at = lo;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t k = k0; k <= k1; ++k) {
+        uint64_t a = (uint64_t)k << chunk_log2, b = a + ((1ull << chunk_log2) - 1);
+        if (a < lo) a = lo;
+        if (b > hi) b = hi;
+        uint64_t s1 = 0, s2 = 0;
+        double lw = -1.0;
+        uint32_t lx = (uint32_t)a;
+        for (uint64_t u = a; u <= b; ++u) {
+            const uint32_t y = fg_f2u(og_math_fn(fn, fg_u2f((uint32_t)u)));
+            s1 += y;
+            s2 += (uint64_t)y * (uint64_t)((uint32_t)u | 1u);
+            if (max_ulp) {
+                const double ex = og_math_ref(fn, (double)fg_u2f((uint32_t)u));
+                int e;
+                (void)frexp(ex, &e);
+                double ulp = ldexp(1.0, e - 24);
+                if (ulp < 0x1p-149) ulp = 0x1p-149;
+                const double err = fabs((double)fg_u2f(y) - ex) / ulp;
+                if (err > lw) { lw = err; lx = (uint32_t)u; }
+            }
+        }
+        out[2 * (k - k0)] = s1;
+        out[2 * (k - k0) + 1] = s2;
+        if (max_ulp) {
+#pragma omp critical
+            if (lw > worst || (lw == worst && lx < worst_at)) { worst = lw; worst_at = lx; }
         }
     }
+    if (max_ulp) { *max_ulp = worst; *argmax = worst_at; }
 }
 
 /* raw Philox4x32-10 block (Random123 known-answer vectors, tests/test_math.py) */

@@ -52,6 +52,7 @@ def lib():
                                             C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
         _lib.og_math_apply.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+        _lib.og_math_checksums.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.og_num_threads.restype = C.c_int
         _lib.og_philox.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.og_bp2_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -107,12 +108,28 @@ def philox(ctr, key):
     return o
 
 
+MATH_FUNCTIONS = {"exp": 0, "log": 1, "log1p": 2, "softplus": 3, "phi": 4, "tanh": 5, "atanh": 6, "phi_gnn": 7, "lse2_corr": 8,
+                  "sigmoid": 9, "div3": 10, "rcp_unit": 11, "div_atanh": 12, "lse2_1": 13}
+
+
 def math_apply(name, x):
-    fn = {"exp": 0, "log": 1, "log1p": 2, "softplus": 3, "phi": 4, "tanh": 5, "atanh": 6}[name]
+    fn = MATH_FUNCTIONS[name]
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = np.empty_like(x)
     lib().og_math_apply(fn, _p(x), _p(y), x.size)
     return y
+
+
+def math_checksums(name, lo, hi, chunk_log2=22, ulp=False):
+    """Exhaustive probe of one shared-math function over the float32 bit patterns lo..hi: uint64 [windows, 2] checksums of the result
+    bits per aligned window of 2^chunk_log2 inputs (og_math_checksums), and with ``ulp`` the largest error against float64 libm in
+    float32 ulps and the input bits where it occurs."""
+    lo, hi = int(lo), int(hi)
+    nwin = (hi >> chunk_log2) - (lo >> chunk_log2) + 1
+    out = np.zeros((nwin, 2), dtype=np.uint64)
+    worst, at = C.c_double(-1.0), C.c_uint32(0)
+    lib().og_math_checksums(MATH_FUNCTIONS[name], lo, hi, int(chunk_log2), _p(out), C.byref(worst) if ulp else None, C.byref(at) if ulp else None)
+    return (out, float(worst.value), int(at.value)) if ulp else out
 
 
 class OracleGraph:

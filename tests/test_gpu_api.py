@@ -285,6 +285,25 @@ def test_sim_ber_fused_launches_equal_the_per_batch_path():
     assert calls and max(calls) == 8  # 4000 // 500 batches per launch
 
 
+def test_sim_ber_with_side_streams_equals_one_stream():
+    """A `streams=2` / `streams=3` model under `sim_ber` (device-counter path, with and without fused launches): the snapshots of the
+    shared counters are ordered behind the side streams, so every counter, status and the stream position equal the one-stream
+    model's — round-4 advisor finding: the ring copies used to race with the side streams' atomic adds."""
+    c = code("ghp882")
+    pts, kw = [0.13, 0.10], dict(batch_size=700, max_mc_iter=30, num_target_block_errors=80, verbose=False, early_stop=False)
+    res = {}
+    for streams in (1, 2, 3):
+        for fuse in (0, 2800):
+            m = _model(c, [64, 16], compact=True, streams=streams, seed=5)
+            F.sim_ber(m, pts, fuse_samples=fuse, **kw)
+            assert F.sim_ber.last["device_counters"]
+            res[(streams, fuse)] = ({k: np.array(F.sim_ber.last[k]).tolist() for k in ("flag_errors", "block_errors", "num_blocks", "status")},
+                                    m._next_sample)
+    assert res[(1, 0)][0]["status"][0] == 4
+    for k, v in res.items():
+        assert v == res[(1, 0)], (k, v, res[(1, 0)])
+
+
 def test_fixed_weight_noise_and_failure_harvesting():
     """Pauli(wt=True) (pauli.py:80-97) and the dataset-harvesting flow of examples/Generate_dataset.ipynb."""
     c = code("ghp882")
