@@ -66,12 +66,24 @@ HW_TRANSCENDENTAL_PEAK = 1024 * 64 * 2.4e9 / 8  # 1.966e13 evaluations/s
 GNN_PEAK_TFLOPS = 157.3  # same guide: f32 MFMA (= f32 vector) peak
 
 CONFIGS = {
-    "c1": dict(code="ghp882", iters="32", batch=256, p=0.05, baseline="configs[0]: the reference's own CPU-runnable case"),
+    # configs[0] as the reference CONSTRUCTS it: QLDPCBPDecoder's defaults cn_type='boxplus', normalization_factor=0.625 (decoding_q.py:18-22);
+    # `--cn-type boxplus-phi` is the QLDPC.ipynb cell 11 helper's variant of the same case
+    "c1": dict(code="ghp882", iters="32", batch=256, p=0.05, cn_type="boxplus", factor=0.625,
+               baseline="configs[0]: the reference's own CPU-runnable case"),
     "c2": dict(code="ghp882", iters="64", batch=65536, baseline="configs[1]: BP4 alone"),
     "c3": dict(code="ghp882", iters="64,16", batch=65536, baseline="configs[2]"),
     "c4": dict(code="ghp1270", iters="64,64", batch=32768, baseline="configs[3], per-GPU shard 262 144 / 8"),
     "c5": dict(code="ghp1270", iters="10", batch=16384, baseline="configs[4], per-GPU shard 131 072 / 8"),
+    # the workloads the reference's only published timings were taken on (RTX 4090, TF-XLA, batch_size 5 000)
+    "n882_3r": dict(code="ghp882", iters="64,16,16,16", batch=5000, p=0.05,
+                    baseline="none — the reference's published workload examples/n882.ipynb cell 2 (n882.py:45-66 with nG = 3), 10.9 k cw/s on an RTX 4090"),
+    "n882_5r": dict(code="ghp882", iters="64,16,16,16,16,16", batch=5000, p=0.05,
+                    baseline="none — the reference's published workload n882.py:13,45-66 (nG = 5; examples/n882.ipynb cell 3), 7.50 k cw/s on an RTX 4090"),
+    "n1270_3r": dict(code="ghp1270", iters="64,16,16,16", batch=5000, p=0.07,
+                     baseline="none — the reference's published workload examples/n1270.ipynb cell 2 (n1270.py:57-70 with nG = 3), 6.39 k cw/s on an RTX 4090"),
 }
+PUBLISHED_CONFIGS = ("n882_3r", "n882_5r", "n1270_3r")
+CN_TYPES = ("boxplus", "boxplus-phi", "minsum")
 PROF_TAG_GNN, PROF_TAG_GNNBP4 = -1, -2  # fgnn_profile_read tags (include/fgnn.h)
 
 
@@ -82,7 +94,7 @@ def algorithmic_bytes_per_codeword(n, m, E, iters):
     return per_iter * iters + epilogue
 
 
-def bp4_transcendentals_per_codeword(n, m, E, iters, shared_lse=True):
+def bp4_transcendentals_per_codeword(n, m, E, iters, shared_lse=True, cn_type="boxplus-phi"):
     """(exp, log) evaluations of one fixed-dataflow BP4 decode (boxplus-phi) per codeword.  Per iteration: the qubit update — two
     softplus per qubit (exp + log1p each, decoding_q.py:265,270) and one log-sum-exp (exp + log) per edge (:266,:271), or per qubit and
     side in the shared form — and the check update — two phi per edge (decoding_q.py:405-429), a phi being one exp, one log1p and one
@@ -90,7 +102,10 @@ def bp4_transcendentals_per_codeword(n, m, E, iters, shared_lse=True):
     of the two soft-syndrome row sets (stage-one: hz and hx, E entries, m rows).  [[882,24]], shared form: 16 exp + 28 log per
     qubit-iteration."""
     lse = 2 * n if shared_lse else E
-    exp_it, log_it = 2 * n + lse + 2 * E, 2 * n + lse + 4 * E
+    # check update: 'boxplus-phi' two phi per edge; 'boxplus' one tanh (a rational: no exp / log) and one atanh (one log1p) per edge
+    # (decoding_q.py:313-363); 'minsum' none (:539-644)
+    cn_exp, cn_log = {"boxplus-phi": (2 * E, 4 * E), "boxplus": (0, E), "minsum": (0, 0)}[cn_type]
+    exp_it, log_it = 2 * n + lse + cn_exp, 2 * n + lse + cn_log
     exp_ep, log_ep = 4 * n + (E + m), 4 * n + 2 * (E + m)
     return exp_it * iters + exp_ep, log_it * iters + log_ep
 
@@ -157,6 +172,16 @@ def parse_args(argv=None):
     ap.add_argument("--p", type=float, default=None, help="depolarizing probability (default: the configuration's, 0.01 unless it names one)")
     ap.add_argument("--code", default=None, choices=["ghp882", "ghp1270"], help="default: the configuration's")
     ap.add_argument("--iters", default=None, help="BP iterations per stage (c5: GNN_BP4 iterations); default: the configuration's")
+    ap.add_argument("--cn-type", default=None, choices=CN_TYPES,
+                    help="check-node rule of every decoder of the sandwich (decoding_q.py:18: the class default is 'boxplus'; the reference's "
+                         "scripts and notebooks construct 'boxplus-phi', n882.py:61, QLDPC.ipynb cell 11); default: the configuration's "
+                         "(c1: 'boxplus', every other: 'boxplus-phi')")
+    ap.add_argument("--factor", type=float, default=None,
+                    help="normalization_factor of every decoder (decoding_q.py:22: class default 0.625; n882.py:58-59: 1.0); default: the "
+                         "configuration's (c1: 0.625, every other: 1.0)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams consecutive batches alternate between (Sandwich_BP_GNN_Evaluation_Model(streams=)); the published-workload "
+                         "configurations time 1 and 2 in the same run")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="codewords for the CPU baseline (0 = skip, -1 = sized from a probe to ~12 s of CPU work)")
     ap.add_argument("--cpu-baseline", default="both", choices=["both", "port", "torch", "none"],
@@ -176,6 +201,10 @@ def parse_args(argv=None):
     args.code = cfg["code"] if args.code is None else args.code
     args.iters = cfg["iters"] if args.iters is None else args.iters
     args.p = cfg.get("p", 0.01) if args.p is None else args.p
+    args.cn_type = cfg.get("cn_type", "boxplus-phi") if args.cn_type is None else args.cn_type
+    args.factor = cfg.get("factor", 1.0) if args.factor is None else args.factor
+    if args.streams < 1:
+        ap.error("--streams must be >= 1")
     return args
 
 
@@ -287,25 +316,26 @@ def cpu_legs(args, code, wname, iters, seed, factored):
     og.set_gnn_order(factored)
     og.set_vn_shared_lse(shared)
     nl = len(iters)
+    fcs, cts = [args.factor] * nl, [args.cn_type] * nl  # every decoder of the sandwich is constructed alike (n882.py:61-62)
     if args.cpu_baseline in ("both", "port"):
         S = args.cpu_sample
         if S < 0:  # probe: 2 codewords per thread, then size the sample for ~12 s
             probe = 2 * num_threads()
             ex, ez = og.pauli_noise(seed, args.p, 0, probe)
             sx, sz = og.syndrome(ex, ez)
-            og.sandwich_decode(sx, sz, iters, [w] * (nl - 1), L0)  # also warms the thread pool
+            og.sandwich_decode(sx, sz, iters, [w] * (nl - 1), L0, factors=fcs, cn_types=cts)  # also warms the thread pool
             t = time.perf_counter()
-            og.sandwich_decode(sx, sz, iters, [w] * (nl - 1), L0)
+            og.sandwich_decode(sx, sz, iters, [w] * (nl - 1), L0, factors=fcs, cn_types=cts)
             rate = probe / (time.perf_counter() - t)
             S = int(min(32768, max(512, 12.0 * rate)))
             S -= S % 64
         ex, ez = og.pauli_noise(seed, args.p, 0, 8)
         sx, sz = og.syndrome(ex, ez)
-        og.sandwich_decode(sx, sz, iters, [w] * (nl - 1), L0)  # warm the thread pool
+        og.sandwich_decode(sx, sz, iters, [w] * (nl - 1), L0, factors=fcs, cn_types=cts)  # warm the thread pool
         t = time.perf_counter()
         ex, ez = og.pauli_noise(seed, args.p, 0, S)
         sx, sz = og.syndrome(ex, ez)
-        o = og.sandwich_decode(sx, sz, iters, [w] * (nl - 1), L0)
+        o = og.sandwich_decode(sx, sz, iters, [w] * (nl - 1), L0, factors=fcs, cn_types=cts)
         _, _, fl = og.residual(ex, ez, o["x_hat"], o["z_hat"])
         t_cpu = time.perf_counter() - t
         out["cpu_baseline"] = {"value": S / t_cpu, "unit": "codewords/s", "cores": num_threads(), "host_cpu_share": share,
@@ -316,7 +346,9 @@ def cpu_legs(args, code, wname, iters, seed, factored):
                                        "better CPU program than the reference's TensorFlow graph, which can run on neither box "
                                        "(SURVEY.md §8c); see cpu_baseline_tf_like for the reference-shaped execution"}
         check = (S, o, fl)
-    if args.cpu_baseline in ("both", "torch"):
+    if args.cpu_baseline in ("both", "torch") and args.cn_type == "minsum":
+        pass  # oracle/torch_cpu_baseline.py restates the 'boxplus-phi' and 'boxplus' rules only: no TF-shaped leg for min-sum
+    elif args.cpu_baseline in ("both", "torch"):
         import torch
         from oracle import torch_cpu_baseline as T
         nthr = num_threads()  # the same thread count as the C port
@@ -329,20 +361,20 @@ def cpu_legs(args, code, wname, iters, seed, factored):
         budget_s, max_chunks = (8.0, 8) if args.cpu_sample < 0 else (1e9, max(1, min(args.cpu_sample, 2048) // chunk))
         ex, ez = og.pauli_noise(seed, args.p, 0, 32)
         sx, sz = og.syndrome(ex, ez)
-        T.sandwich_decode(tg, w, sx, sz, [2] * nl, L0)  # warm-up
+        T.sandwich_decode(tg, w, sx, sz, [2] * nl, L0, fcs, cts)  # warm-up
         St, t_t, xs, zs, sxs, szs, chunk_s = 0, 0.0, [], [], [], [], []
         while len(xs) < max_chunks and t_t < budget_s:
             ex, ez = og.pauli_noise(seed, args.p, St, chunk)
             sx, sz = og.syndrome(ex, ez)
             t = time.perf_counter()
-            xh, zh = T.sandwich_decode(tg, w, sx, sz, iters, L0)
+            xh, zh = T.sandwich_decode(tg, w, sx, sz, iters, L0, fcs, cts)
             chunk_s.append(time.perf_counter() - t)
             t_t += chunk_s[-1]
             St += chunk
             xs.append(xh); zs.append(zh); sxs.append(sx); szs.append(sz)
         xh, zh, sx, sz = np.concatenate(xs), np.concatenate(zs), np.concatenate(sxs), np.concatenate(szs)
         torch.set_flush_denormal(False)
-        ref = og.sandwich_decode(sx, sz, iters, [w] * (nl - 1), L0)
+        ref = og.sandwich_decode(sx, sz, iters, [w] * (nl - 1), L0, factors=fcs, cn_types=cts)
         hx, hz = np.asarray(code.hx, dtype=np.int64), np.asarray(code.hz, dtype=np.int64)
 
         def solved(x, z):
@@ -490,7 +522,7 @@ def feedback_gnn_roofline(code_name, dims, launches, B, factored, stream):
         # the default: factored association on the streaming VALU kernel (no MFMA: on gfx950 an f32 MFMA has the f32 VALU's rate and
         # only pads the 40 / 20 / 3-row layers to 16-row tiles).  Priced like the BP4 kernel: VALU wave-instructions per second.
         g_ach = gvi / (gnn_ms * 1e-3) / 1e9 if (gvi and gnn_ms) else None
-        return dict({"bound": "valu", "kernel": f"feedback-GNN streaming VALU kernel (factored association), B={B}",
+        return dict({"bound": "valu", "kernel": f"feedback-GNN streaming VALU kernel ({'factored' if factored else 'literal'} association), B={B}",
                      "achieved": g_ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
                      "frac": g_ach / VALU_PEAK_GINST if g_ach else None}, **common,
                     note="frac = SQ_INSTS_VALU per launch (offline PMC pass, source-fingerprinted) / this run's launch time / "
@@ -505,7 +537,7 @@ def feedback_gnn_roofline(code_name, dims, launches, B, factored, stream):
                      "(one 40->20 Dense per qubit and side) for the same function")
 
 
-def sandwich_roofline(code_name, dims, launches, launches_per_step, B, iters, factored, stream, shared_lse):
+def sandwich_roofline(code_name, dims, launches, launches_per_step, B, iters, factored, stream, shared_lse, cn_type="boxplus-phi"):
     """`roofline` of the c3 / c4 lines: the first decoder's BP4 launch against VALU issue (utilisation) and against the hardware
     transcendental rate (algorithmic efficiency), the SURVEY §8d streaming figure as an effective bandwidth, measured HBM bytes."""
     import numpy as np
@@ -519,16 +551,17 @@ def sandwich_roofline(code_name, dims, launches, launches_per_step, B, iters, fa
     eff_gbs = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
     # VALU instruction counts and HBM bytes per launch are NOT measured by this run: they come from the rocprofv3 PMC passes of
     # tools/refresh_traffic.sh at the same shape, guarded by the fingerprint of the kernel sources (pmc_entry)
-    ent, tsrc = pmc_entry("bp4", f"bp4_{code_name}_it{iters[0]}_B{B}")
+    # one entry per check-node rule (a template argument of the kernel); the normalization factor is a runtime multiplier
+    ent, tsrc = pmc_entry("bp4", f"bp4_{code_name}_it{iters[0]}_B{B}" + ("" if cn_type == "boxplus-phi" else f"_{cn_type}"))
     if ent and not shared_lse:
         ent, tsrc = None, "profiles/traffic.json holds the counts of the default (shared log-sum-exp) form; this run times the literal form"
     traffic = ent.get("hbm_bytes_per_launch") if ent else None
     vi = ent.get("valu_wave_insts_per_launch") if ent else None
     achieved = vi / (dom_ms * 1e-3) / 1e9 if (vi and dom_ms) else None
-    n_exp, n_log = bp4_transcendentals_per_codeword(n, m, E, iters[0], shared_lse)
+    n_exp, n_log = bp4_transcendentals_per_codeword(n, m, E, iters[0], shared_lse, cn_type)
     trans = (n_exp + n_log) * B
     return {"bound": "valu",
-            "kernel": f"bp4_kernel<boxplus-phi>, first decoder (constant channel LLR), {iters[0]} iterations, B={B}",
+            "kernel": f"bp4_kernel<{cn_type}>, first decoder (constant channel LLR), {iters[0]} iterations, B={B}",
             "achieved": achieved, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
             "frac": achieved / VALU_PEAK_GINST if achieved else None,
             "traffic": traffic, "traffic_source": tsrc,
@@ -581,7 +614,7 @@ def gnnbp4_forms_agreement(g, wdev, sx, sz, num_iter, workspace):
             "max_abs_dllr": float(d.max()), "samples_gt_1e_4": int((d > 1e-4).sum())}
 
 
-def sandwich_extras(g, model, code, decs, G, iters, B, p, seed, literal_value):
+def sandwich_extras(g, model, code, decs, G, iters, B, p, seed, literal_value, cn_type="boxplus-phi", factor=1.0):
     """`extras` of a single-GPU c3 / c4 run: the variants that are NOT the headline — BP4 alone (configs[1]), the product default (exact
     shortcuts, compaction: identical outputs) and the opt-in hardware-transcendental BP4 with its measured distance from the exact kernel."""
     import numpy as np
@@ -600,9 +633,9 @@ def sandwich_extras(g, model, code, decs, G, iters, B, p, seed, literal_value):
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / reps
 
-    t_bp = timed(lambda: g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0))
+    t_bp = timed(lambda: g.bp4_decode(sx, sz, iters[0], cn_type, factor, llr_const=L0))
     g.set_saturation_shortcut(True)
-    t_bp_s = timed(lambda: g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0))
+    t_bp_s = timed(lambda: g.bp4_decode(sx, sz, iters[0], cn_type, factor, llr_const=L0))
     cs = torch.zeros(3, dtype=torch.int64, device="cuda")
     t_s = timed(lambda: model.mc_step(B, p, cs))
     g.set_saturation_shortcut(False)
@@ -622,32 +655,34 @@ def sandwich_extras(g, model, code, decs, G, iters, B, p, seed, literal_value):
         model_2s.join()
 
     t_2s = timed(two_stream_steps) / 2
-    # OPT-IN variant, never the headline: the phi rule on v_exp_f32 / v_log_f32 (FGNN_OPT_HW_TRANSCENDENTALS), and how
-    # far its results are from the exact kernel's on this very batch — the measured price of bit-exactness
-    exact = g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0)
-    g.set_hw_transcendentals(True)
-    t_hw = timed(lambda: g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0))
-    hw = g.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=L0)
-    g.set_hw_transcendentals(False)
-    same_dec = ((exact["x_hat"] == hw["x_hat"]).all(1) & (exact["z_hat"] == hw["z_hat"]).all(1))
-    ones = torch.ones(B, dtype=torch.uint8, device="cuda")
-    conv_e = g.flag_update(exact["x_hat"], exact["z_hat"], sx, sz, ones.clone()) == 0
-    conv_h = g.flag_update(hw["x_hat"], hw["z_hat"], sx, sz, ones.clone()) == 0
-    both = conv_e & conv_h
-    dl = (exact["llr"] - hw["llr"]).abs().flatten(1).max(1).values
-    nb = max(int(both.sum()), 1)
-    # decisions that differ by a stabilizer (difference in the row space of hx / hz <=> zero syndrome under hx_perp / hz_perp)
-    hxp = torch.from_numpy(np.asarray(code.hx_perp)).to("cuda").float()
-    hzp = torch.from_numpy(np.asarray(code.hz_perp)).to("cuda").float()
-    dxb, dzb = (exact["x_hat"] ^ hw["x_hat"])[both].float(), (exact["z_hat"] ^ hw["z_hat"])[both].float()
-    same_class = ~(((dxb @ hxp.t()) % 2).bool().any(1) | ((dzb @ hzp.t()) % 2).bool().any(1))
-    hw_info = {"cw_per_s": B / t_hw, "speedup_vs_exact_kernel": t_bp / t_hw,
-               "samples": B, "converged_exact": int(conv_e.sum()), "converged_hw": int(conv_h.sum()),
-               "identical_decisions_all_samples": float(same_dec.float().mean()),
-               "identical_decisions_on_samples_both_converge": float(same_dec[both].float().mean()) if int(both.sum()) else None,
-               "same_correction_class_on_samples_both_converge": float(same_class.double().mean()) if int(both.sum()) else None,
-               "max_abs_llr_diff_le_1e-4_on_samples_both_converge": float((dl[both] <= 1e-4).sum()) / nb,
-               "median_abs_llr_diff_on_samples_both_converge": float(dl[both].median()) if int(both.sum()) else None}
+    hw_info = None
+    if cn_type == "boxplus-phi":  # the hardware-transcendental variant exists for the phi rule only
+        # OPT-IN variant, never the headline: the phi rule on v_exp_f32 / v_log_f32 (FGNN_OPT_HW_TRANSCENDENTALS), and how
+        # far its results are from the exact kernel's on this very batch — the measured price of bit-exactness
+        exact = g.bp4_decode(sx, sz, iters[0], cn_type, factor, llr_const=L0)
+        g.set_hw_transcendentals(True)
+        t_hw = timed(lambda: g.bp4_decode(sx, sz, iters[0], cn_type, factor, llr_const=L0))
+        hw = g.bp4_decode(sx, sz, iters[0], cn_type, factor, llr_const=L0)
+        g.set_hw_transcendentals(False)
+        same_dec = ((exact["x_hat"] == hw["x_hat"]).all(1) & (exact["z_hat"] == hw["z_hat"]).all(1))
+        ones = torch.ones(B, dtype=torch.uint8, device="cuda")
+        conv_e = g.flag_update(exact["x_hat"], exact["z_hat"], sx, sz, ones.clone()) == 0
+        conv_h = g.flag_update(hw["x_hat"], hw["z_hat"], sx, sz, ones.clone()) == 0
+        both = conv_e & conv_h
+        dl = (exact["llr"] - hw["llr"]).abs().flatten(1).max(1).values
+        nb = max(int(both.sum()), 1)
+        # decisions that differ by a stabilizer (difference in the row space of hx / hz <=> zero syndrome under hx_perp / hz_perp)
+        hxp = torch.from_numpy(np.asarray(code.hx_perp)).to("cuda").float()
+        hzp = torch.from_numpy(np.asarray(code.hz_perp)).to("cuda").float()
+        dxb, dzb = (exact["x_hat"] ^ hw["x_hat"])[both].float(), (exact["z_hat"] ^ hw["z_hat"])[both].float()
+        same_class = ~(((dxb @ hxp.t()) % 2).bool().any(1) | ((dzb @ hzp.t()) % 2).bool().any(1))
+        hw_info = {"cw_per_s": B / t_hw, "speedup_vs_exact_kernel": t_bp / t_hw,
+                   "samples": B, "converged_exact": int(conv_e.sum()), "converged_hw": int(conv_h.sum()),
+                   "identical_decisions_all_samples": float(same_dec.float().mean()),
+                   "identical_decisions_on_samples_both_converge": float(same_dec[both].float().mean()) if int(both.sum()) else None,
+                   "same_correction_class_on_samples_both_converge": float(same_class.double().mean()) if int(both.sum()) else None,
+                   "max_abs_llr_diff_le_1e-4_on_samples_both_converge": float((dl[both] <= 1e-4).sum()) / nb,
+                   "median_abs_llr_diff_on_samples_both_converge": float(dl[both].median()) if int(both.sum()) else None}
     return {"bp4_only_cw_per_s (configs[1])": B / t_bp,
             "bp4_only_HW_TRANSCENDENTALS_opt_in_NOT_bit_exact (v_exp_f32/v_log_f32, phi clip points pinned, fixed dataflow)": hw_info,
             "bp4_only_product_default_cw_per_s (exact saturation shortcut + fixed-point exit, identical outputs)": B / t_bp_s,
@@ -681,8 +716,9 @@ def main():
     iters = [int(x) for x in args.iters.split(",")]
     code, wname = make_code(args.code)
     factored = os.environ.get("FGNN_BENCH_GNN_ORDER", "factored") != "literal"  # the library default; "literal" times the other order
-    # the factored order runs on the streaming VALU kernel by default; FGNN_BENCH_GNN_KERNEL=mfma times the MFMA-tile kernel
-    stream = factored and os.environ.get("FGNN_BENCH_GNN_KERNEL", "stream") != "mfma"
+    # both associations run on the streaming VALU kernel by default (the library's choice at these batch sizes);
+    # FGNN_BENCH_GNN_KERNEL=mfma times the MFMA-tile kernel
+    stream = os.environ.get("FGNN_BENCH_GNN_KERNEL", "stream") != "mfma"
     shared_lse = os.environ.get("FGNN_BENCH_BP4_LSE", "shared") != "literal"    # likewise for the qubit update's log-sum-exp term
     c5_weights = gnnbp4_seeded_weights(0) if is_c5 else None
 
@@ -714,6 +750,27 @@ def main():
         except Exception as e:  # this process is a fresh child (launch_ranks / torchrun): report and leave with a non-zero code
             sys.stderr.write(f"bench.py: rank {rank}: init_process_group({backend}) failed: {e}\n")
             sys.exit(3)
+
+    # ---- pre-flight of the multi-GPU run (the reference pins one process per GPU id, n882.py:9-25): every rank reports the device it
+    # really sits on; a rank that is not on cuda:LOCAL_RANK under RCCL leaves with its own non-zero code, and rank 0 prints the map
+    if backend == "nccl" and torch.cuda.current_device() != local_rank:
+        sys.stderr.write(f"bench.py: rank {rank}: on cuda:{torch.cuda.current_device()}, expected cuda:{local_rank}\n")
+        sys.exit(6)
+    props = torch.cuda.get_device_properties(dev_index)
+    me = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device_name": torch.cuda.get_device_name(dev_index),
+          "device_uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None), "pid": os.getpid()}
+    ranks_info = [me]
+    if dist is not None:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
+    distinct = len({(r["device_uuid"], r["pci_bus_id"], r["device_index"]) for r in ranks_info}) == world
+    dist_info = {"world_size": dist.get_world_size() if dist is not None else 1,
+                 "backend": dist.get_backend() if dist is not None else None,
+                 "collective_library": ("RCCL (torch.distributed backend 'nccl' on ROCm)" if backend == "nccl" else backend) if dist is not None else None,
+                 "ranks": ranks_info, "one_distinct_device_per_rank": distinct}
+    if dist is not None and backend == "nccl" and not distinct:
+        sys.stderr.write(f"bench.py: rank {rank}: the {world} ranks do not sit on {world} distinct devices: {ranks_info}\n")
+        sys.exit(7)
 
     def allreduce(t, op):
         if backend == "nccl":
@@ -763,19 +820,25 @@ def main():
         launches_per_step = 1
         model = decs = G = None
     else:
-        decs = [F.QLDPCBPDecoder(code=code, num_iter=iters[0], normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True)]
+        decs = [F.QLDPCBPDecoder(code=code, num_iter=iters[0], normalization_factor=args.factor, cn_type=args.cn_type, stage_one=True)]
         g = decs[0].graph
         g.set_gnn_factored(factored)
         g.set_gnn_stream(stream)
+        # which kernel that selects: the library streams launches of 4 096 codewords or more, smaller ones run on the MFMA tiles
+        # (fgnn_gnn.hip `stream_pays`: FGNN_OPT_GNN_STREAM = 1) — the labels and the roofline below name the kernel that runs
+        stream = stream and B >= 4096
         g.set_bp4_shared_lse(shared_lse)
         for it in iters[1:]:
-            decs.append(F.QLDPCBPDecoder(code=code, num_iter=it, normalization_factor=1.0, cn_type="boxplus-phi",
+            decs.append(F.QLDPCBPDecoder(code=code, num_iter=it, normalization_factor=args.factor, cn_type=args.cn_type,
                                          stage_one=True, graph=g))
         G = F.Feedback_GNN(code=code, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean",
                            activation="tanh", use_bias=True, graph=g)
         F.load_weights(G, wname)
-        model = F.Sandwich_BP_GNN_Evaluation_Model(code, decs, [G] * (len(iters) - 1), num_layers=len(iters), p0=0.05, seed=SEED,
-                                                   rank=rank, world_size=world)
+        def make_model(streams):
+            return F.Sandwich_BP_GNN_Evaluation_Model(code, decs, [G] * (len(iters) - 1), num_layers=len(iters), p0=0.05, seed=SEED,
+                                                      rank=rank, world_size=world, streams=streams)
+
+        model = make_model(args.streams)
 
         def step(counts):
             model.mc_step(B, args.p, counts)
@@ -790,8 +853,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_region(steps, profile):
-        """EXACTLY `steps` steps between barrier + synchronize on both sides; (max-over-ranks seconds, this rank's seconds, launches)."""
+    def timed_region(steps, profile, step=step):
+        """EXACTLY `steps` steps between barrier + synchronize on both sides (the device-wide synchronize also waits for a model's side
+        streams); (max-over-ranks seconds, this rank's seconds, launches)."""
         counts = torch.zeros(3, dtype=torch.int64, device="cuda")
         if profile:
             g.profile_enable(steps * launches_per_step)
@@ -834,6 +898,23 @@ def main():
                                + ("GNN_BP4 message MLP once per edge (gnn.py:573-610, 714-751), FGNN_OPT_GNN_FACTORED = 0" if is_c5 else
                                   "one log-sum-exp per edge in the qubit update (decoding_q.py:254-273, FGNN_OPT_BP4_SHARED_LSE = 0) and one "
                                   "40 -> 20 Dense per edge in the feedback GNN (feedback_gnn.py:175-184, FGNN_OPT_GNN_FACTORED = 0)")}
+        # ---- the reference's published workloads run 5 000-codeword batches (n882.py:39): one such batch fills a fraction of the chip,
+        # so the same step is also timed with consecutive batches alternating between two HIP streams (same samples, same counters)
+        other_streams = None
+        if args.config in PUBLISHED_CONFIGS and not is_c5:
+            ns = 1 if args.streams > 1 else 2
+            model_o = make_model(ns)
+
+            def step_o(counts):
+                model_o.mc_step(B, args.p, counts)
+
+            for _ in range(max(W, 2)):
+                step_o(torch.zeros(3, dtype=torch.int64, device="cuda"))
+            o_elapsed, _, _, o_counts = timed_region(K, False, step_o)
+            other_streams = {"streams": ns, "value": world * B * K / o_elapsed, "unit": "codewords/s", "ms_per_step": o_elapsed / K * 1e3,
+                             "steps": K, "what": f"the same step on Sandwich_BP_GNN_Evaluation_Model(streams={ns}): "
+                                                 + ("consecutive batches alternate between two HIP streams (own workspaces, shared atomic "
+                                                    "counters), fixed dataflow, same Philox samples" if ns == 2 else "one stream")}
     except Exception as e:
         if dist is None:
             raise
@@ -867,23 +948,31 @@ def main():
             is_cfg_shape = args.code == cfg["code"] and args.iters == cfg["iters"]
             nk = "[[882,24]]" if args.code == "ghp882" else "[[1270,28]]"
             metric = (f"decoded codewords/sec, {nk} BP4 {iters[0]} iters" if len(iters) == 1 else
+                      f"decoded codewords/sec, {nk} BP4-{iters[0]} + {len(iters) - 1} x (feedback-GNN + BP4-{iters[1]})" if len(iters) > 2 else
                       "decoded codewords/sec, [[882,24]] 64-iter BP4 + feedback-GNN" if args.code == "ghp882" else
                       "decoded codewords/sec, [[1270,28]] BP4 64+64 iters w/ feedback-GNN")
+            ref_construction = ("the reference's constructor defaults, decoding_q.py:18-22" if (args.cn_type, args.factor) == ("boxplus", 0.625) else
+                                "as the reference's scripts construct it, n882.py:56-62" if (args.cn_type, args.factor) == ("boxplus-phi", 1.0) else
+                                "the QLDPC.ipynb cell 11 helper's construction" if (args.cn_type, args.factor) == ("boxplus-phi", 0.625) else
+                                "construction given on the command line")
             out = dict({"metric": metric}, **common, **{
                 "config": {"workload": (f"{code.name} BP4-{iters[0]} alone (one QLDPCBPDecoder launch per step), " if len(iters) == 1 else
                                         f"{code.name} sandwich BP4-{'+'.join(map(str, iters))} with {len(iters) - 1} feedback-GNN "
                                         f"pass(es), trained weights {wname}, ") +
-                                       f"boxplus-phi, factor 1.0, p0=0.05, depolarizing p={args.p}, "
+                                       f"cn_type={args.cn_type}, normalization_factor={args.factor} ({ref_construction}), p0=0.05, "
+                                       f"depolarizing p={args.p}, "
                                        f"noise+syndrome+decode+residual+count on device (BASELINE.json "
                                        f"{cfg['baseline'] if is_cfg_shape else 'shape given on the command line'})",
                            "code": code.name, "batch_per_gpu": B, "global_batch": world * B, "bp_iters": iters, "p": args.p,
+                           "cn_type": args.cn_type, "normalization_factor": args.factor, "streams": args.streams,
                            "parallelism": f"batch-sharded x{world}, no data-path collective",
                            "threads_per_codeword": info["threads_per_codeword"], "seed": SEED,
                            "gnn_association": "factored" if factored else "literal",
                            "gnn_kernel": "streaming VALU" if stream else "MFMA tiles",
                            "bp4_qubit_update_lse": "shared per qubit side" if shared_lse else "per edge (literal)"},
                 "per_rank_ms": per_rank_ms,
-                "roofline": sandwich_roofline(args.code, (n, m, E), launches, launches_per_step, B, iters, factored, stream, shared_lse),
+                "roofline": sandwich_roofline(args.code, (n, m, E), launches, launches_per_step, B, iters, factored, stream, shared_lse,
+                                              args.cn_type),
                 "counts": counts_obj})
         if literal is not None:
             out["literal_forms"] = literal
@@ -893,6 +982,13 @@ def main():
             out["literal_forms"] = {"value": value, "ms_per_step": elapsed / K * 1e3, "unit": "codewords/s",
                                     "what": "the headline of this run IS the literal forms (FGNN_BENCH_BP4_LSE / FGNN_BENCH_GNN_ORDER = literal)"}
         out.update(cpu_out)
+        out["dist"] = dist_info
+        if other_streams is not None:
+            out["two_streams" if other_streams["streams"] == 2 else "one_stream"] = other_streams
+        out["value_is"] = ("the library's default operation sequence (two re-associations of the reference's formulas on: identical decisions to the "
+                           "literal forms on every sample at p <= 0.02, statistically the same decoder in the waterfall — see forms_agreement at "
+                           "this run's p); literal_forms.value is the same step with the reference's formulas term by term"
+                           if (factored or (shared_lse and not is_c5)) else "the reference's formulas term by term (literal forms)")
 
     if rank == 0 and args.no_literal:
         out["forms_agreement"] = None
@@ -904,7 +1000,8 @@ def main():
         if is_c5:
             fa = gnnbp4_forms_agreement(g, wdev, sx, sz, iters[0], ws)
         else:
-            fa = g.forms_agreement(sx, sz, iters, [G.device_weights] * (len(iters) - 1), llr_const(0.05))
+            fa = g.forms_agreement(sx, sz, iters, [G.device_weights] * (len(iters) - 1), llr_const(0.05),
+                                   factors=[args.factor] * len(iters), cn_types=[args.cn_type] * len(iters))
         fa["p"] = args.p
         fa["what"] = ("the first timed batch of rank 0 decoded under the default forms and under the literal forms (both this library's "
                       "kernels, each bit-equal to the oracle's restatement of its form): samples whose final decisions differ, max over "
@@ -937,7 +1034,8 @@ def main():
         if "cpu_baseline_tf_like" in out:
             out["speedup_vs_cpu_tf_like"] = value / out["cpu_baseline_tf_like"]["value"]
         if not args.no_extras and not is_c5:
-            out["extras"] = sandwich_extras(g, model, code, decs, G, iters, B, args.p, SEED, (out["literal_forms"] or {}).get("value"))
+            out["extras"] = sandwich_extras(g, model, code, decs, G, iters, B, args.p, SEED, (out["literal_forms"] or {}).get("value"),
+                                            args.cn_type, args.factor)
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()

@@ -537,7 +537,7 @@ class TannerGraph:
             out["rounds"] = rounds
         return out
 
-    def forms_agreement(self, synd_x, synd_z, iters, weights_list, llr_const, chunk=16384):
+    def forms_agreement(self, synd_x, synd_z, iters, weights_list, llr_const, chunk=16384, factors=None, cn_types=None):
         """The sandwich on the same syndromes under the library's default operation sequence and under the reference's formulas
         term by term (options 4 and 5 = 0: one Dense per edge, feedback_gnn.py:175-184; one log-sum-exp per edge,
         decoding_q.py:254-273), compared per sample: how many samples end on different decisions, how far the marginals of the
@@ -545,6 +545,8 @@ class TannerGraph:
         BP does not converge on is chaotic under ANY change of float32 rounding).  Both runs are this library's
         kernels, each bit-equal to the oracle's restatement of its form; the settings in force are restored."""
         B = int(synd_x.shape[0])
+        factors = [1.0] * len(iters) if factors is None else list(factors)
+        cn_types = ["boxplus-phi"] * len(iters) if cn_types is None else list(cn_types)
         prev = (self.gnn_factored, self.bp4_shared_lse)
         res = dict(samples=B, decisions_differ=0, max_abs_dllr=0.0, samples_gt_1e_4=0, max_abs_dllr_solved=0.0,
                    samples_gt_1e_4_solved=0, flagged_default=0, flagged_literal=0, flagged_in_one_form_only=0,
@@ -557,9 +559,9 @@ class TannerGraph:
                 for default in (True, False):
                     self.set_gnn_factored(prev[0] if default else False)
                     self.set_bp4_shared_lse(prev[1] if default else False)
-                    o = self.sandwich_decode(sx, sz, iters, weights_list, llr_const, return_llr=True)
+                    o = self.sandwich_decode(sx, sz, iters, weights_list, llr_const, factors=factors, cn_types=cn_types, return_llr=True)
                     o["flag"] = self.flag_update(o["x_hat"], o["z_hat"], sx, sz, ones.clone()) != 0
-                    o["first"] = self.bp4_decode(sx, sz, iters[0], "boxplus-phi", 1.0, llr_const=llr_const, want_logits=False)
+                    o["first"] = self.bp4_decode(sx, sz, iters[0], cn_types[0], factors[0], llr_const=llr_const, want_logits=False)
                     outs.append(o)
                 a, b = outs
                 differ = (a["x_hat"] != b["x_hat"]).any(1) | (a["z_hat"] != b["z_hat"]).any(1)

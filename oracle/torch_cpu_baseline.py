@@ -20,8 +20,12 @@ a host: batch-minor float32 tensors [E, B], one framework op at a time, every in
 with torch's own exp / log / log1p / tanh and `torch.set_num_threads(all cores)`.  Results agree with the C oracle the way two
 faithful float32 implementations do (identical decisions on converged samples); bench.py checks that on every run.
 """
+import warnings
+
 import numpy as np
 import torch
+
+warnings.filterwarnings("ignore", message="index_reduce")
 
 F = torch.float32
 _THR = float(np.float32(np.log(np.finfo(np.float32).eps, dtype=np.float32) + np.float32(2.0)))  # tf2xla Softplus threshold (negative)
@@ -87,15 +91,31 @@ def _cn_phi(nu_cn, side, sigma, factor):
     return sgn * prod[side["cn_of"]] * phi(T[side["cn_of"]] - a) * factor
 
 
+def _cn_tanh(nu_cn, side, sigma, factor):
+    """cn_type='boxplus', decoding_q.py:313-363: tanh(msg / 2), exact zeros -> 1e-12, ragged reduce_prod times the syndrome sign,
+    own edge divided out (msg**-1), |.| < 1e-7 -> 0, clip to +-(1 - 1e-7), 2 atanh."""
+    t = torch.tanh(nu_cn / 2)
+    t = torch.where(t == 0, torch.full_like(t, 1e-12), t)
+    prod = torch.ones((side["m"], t.shape[1]), dtype=F).index_reduce_(0, side["cn_of"], t, "prod") * sigma
+    q = t ** -1 * prod[side["cn_of"]]
+    q = torch.where(torch.abs(q) < 1e-7, torch.zeros_like(q), q)
+    q = torch.clamp(q, -(1.0 - 1e-7), 1.0 - 1e-7)
+    return 2 * torch.atanh(q) * factor
+
+
+CN_RULES = {"boxplus-phi": _cn_phi, "boxplus": _cn_tanh}
+
+
 def _logits(rows, llr):
     v = llr[rows["col"]]
     prod = _seg_sign(v < 0, rows["row"], rows["rows"])
     return prod * phi(_seg_sum(phi(torch.abs(v)), rows["row"], rows["rows"]))
 
 
-def bp4_decode(g, synd_x, synd_z, num_iter, llr_ch, factor=1.0):
+def bp4_decode(g, synd_x, synd_z, num_iter, llr_ch, factor=1.0, cn_type="boxplus-phi"):
     """synd_* [m,B] (0/1 float), llr_ch [3,n,B] -> X, Y, Z [n,B], x_hat, z_hat [n,B] int64, x_logit [m_z,B], z_logit [m_x,B]."""
     B = synd_x.shape[1]
+    cn_rule = CN_RULES[cn_type]
     sig = [1.0 - 2.0 * synd_x, 1.0 - 2.0 * synd_z]
     msg = [torch.zeros((s["var"].numel(), B), dtype=F) for s in g.sides]
 
@@ -111,7 +131,7 @@ def bp4_decode(g, synd_x, synd_z, num_iter, llr_ch, factor=1.0):
         nuz = softplus(-Z)[vz] - lse2(-(X[vz] - msg[1]), -(Y[vz] - msg[1]))
         for s, nu in ((0, nux), (1, nuz)):
             side = g.sides[s]
-            msg[s] = _cn_phi(nu[side["to_cn"]], side, sig[s], factor)[side["inv"]]
+            msg[s] = cn_rule(nu[side["to_cn"]], side, sig[s], factor)[side["inv"]]
     X, Y, Z = totals()
     dec = torch.argmin(torch.stack([torch.zeros_like(X), X, Z, Y], 0), dim=0)
     x_hat = dec % 2
@@ -137,7 +157,7 @@ def feedback_gnn(g, w, X, Y, Z, logit_hx, logit_hz, synd_x, synd_z):
     return o.permute(2, 1, 0).contiguous()
 
 
-def sandwich_decode(g, weights, synd_x, synd_z, iters, llr_const, factors=None):
+def sandwich_decode(g, weights, synd_x, synd_z, iters, llr_const, factors=None, cn_types=None):
     """Sandwich_BP_GNN_Evaluation_Model.call from the syndromes on (feedback_gnn.py:311-340).  synd_* uint8 [B,m] codeword-major
     (as the oracle takes them); returns x_hat, z_hat uint8 [B,n]."""
     w = [torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)) for a in weights] if weights is not None else None
@@ -146,14 +166,15 @@ def sandwich_decode(g, weights, synd_x, synd_z, iters, llr_const, factors=None):
     sxf, szf = sx.to(F), sz.to(F)
     B = sx.shape[1]
     factors = [1.0] * len(iters) if factors is None else factors
+    cn_types = ["boxplus-phi"] * len(iters) if cn_types is None else cn_types
     llr = torch.full((3, g.n, B), float(llr_const), dtype=F)
-    X, Y, Z, xh, zh, xl, zl = bp4_decode(g, sxf, szf, iters[0], llr, factors[0])
+    X, Y, Z, xh, zh, xl, zl = bp4_decode(g, sxf, szf, iters[0], llr, factors[0], cn_types[0])
     errors = torch.ones(B, dtype=torch.bool)
     for i in range(1, len(iters)):
         flag = ((g.hz @ xh) % 2 != sz.to(torch.int64)).any(0) | ((g.hx @ zh) % 2 != sx.to(torch.int64)).any(0)
         errors = errors & flag
         llr = feedback_gnn(g, w, X, Y, Z, zl, xl, sxf, szf)  # the logit swap of feedback_gnn.py:335
-        X, Y, Z, xn, zn, xl, zl = bp4_decode(g, sxf, szf, iters[i], llr, factors[i])
+        X, Y, Z, xn, zn, xl, zl = bp4_decode(g, sxf, szf, iters[i], llr, factors[i], cn_types[i])
         xh = torch.where(errors[None, :], xn, xh)
         zh = torch.where(errors[None, :], zn, zh)
     return xh.t().contiguous().to(torch.uint8).numpy(), zh.t().contiguous().to(torch.uint8).numpy()

@@ -48,14 +48,17 @@ def test_bench_prints_one_contract_line():
     assert r["launches_timed"] == 2 and r["hbm_peak_GBs"] == 8000.0
     eff = r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9
     assert abs(r["effective_bandwidth_GBs"] - eff) < 1e-6 * eff and abs(r["effective_bandwidth_frac"] - eff / 8000.0) < 1e-9
-    gn = r["gnn"]  # the second kernel's roofline (the streaming VALU kernel by default), timed in the same run by the same HIP-event recorder
-    assert gn["bound"] == "valu" and gn["unit"] == "G wave-instructions/s" and gn["peak"] == 1228.8 and gn["launches_timed"] == 2
-    assert gn["frac"] is None and gn["achieved"] is None and "no entry" in gn["traffic_source"]  # no PMC counts at this small batch
+    # the second kernel's roofline, timed in the same run by the same HIP-event recorder: at 2 048 codewords the library runs the feedback
+    # GNN on its MFMA tiles (the streaming VALU kernel takes over from 4 096 on), priced in the reference's FLOPs against the f32 peak
+    gn = r["gnn"]
+    assert gn["bound"] == "mfma" and gn["unit"] == "TFLOP/s" and gn["peak"] == 157.3 and gn["launches_timed"] == 2
+    assert "MFMA-tile" in gn["kernel"] and gn["traffic"] is None and "no entry" in gn["traffic_source"]  # no PMC counts at this small batch
+    assert abs(gn["frac"] - gn["reference_tflops_frac_of_f32_peak"]) < 1e-12 and gn["achieved"] == gn["reference_tflops"]
     assert gn["algorithmic_flops_per_launch"] == 13406400 * 2048 and gn["executed_flops_per_launch"] == 6914880 * 2048
     ref_tf = gn["algorithmic_flops_per_launch"] / (gn["avg_launch_ms"] * 1e-3) / 1e12
     assert abs(gn["reference_tflops"] - ref_tf) < 1e-6 * ref_tf
     assert abs(gn["reference_tflops_frac_of_f32_peak"] - ref_tf / 157.3) < 1e-9 and gn["executed_frac"] < gn["reference_tflops_frac_of_f32_peak"] <= 1.0
-    assert d["config"]["gnn_association"] == "factored" and d["config"]["gnn_kernel"] == "streaming VALU"
+    assert d["config"]["gnn_association"] == "factored" and d["config"]["gnn_kernel"] == "MFMA tiles"  # 2 048 < 4 096 codewords: the library's own choice
     assert d["per_rank_ms"] == [d["ms_per_step"]]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "codewords/s" and c["cores"] >= 1 and c["value"] > 0 and "256 codewords" in c["sample"]
@@ -88,6 +91,18 @@ def test_config_shapes_and_the_algorithmic_counts_of_the_other_two_configs():
     assert a.p == 0.01
     a = bench.parse_args(["--config", "c1"])  # configs[0]: the reference's CPU-runnable case (32 iterations, 256 codewords, p = 0.05)
     assert (a.code, a.iters, a.batch, a.p) == ("ghp882", "32", 256, 0.05) and bench.parse_args(["--config", "c1", "--p", "0.02"]).p == 0.02
+    assert (a.cn_type, a.factor) == ("boxplus", 0.625)  # the reference's constructor defaults (decoding_q.py:18-22)
+    a = bench.parse_args(["--config", "c1", "--cn-type", "boxplus-phi"])  # the QLDPC.ipynb cell 11 helper's variant
+    assert (a.cn_type, a.factor) == ("boxplus-phi", 0.625)
+    a = bench.parse_args([])
+    assert (a.cn_type, a.factor, a.streams) == ("boxplus-phi", 1.0, 1)  # n882.py:56-62
+    # the workloads of the reference's only published timings: n882.py:39,56-66 / n1270.py:57-70 with nG = 3, 5
+    a = bench.parse_args(["--config", "n882_3r"])
+    assert (a.code, a.iters, a.batch, a.p) == ("ghp882", "64,16,16,16", 5000, 0.05)
+    a = bench.parse_args(["--config", "n882_5r"])
+    assert (a.code, a.iters, a.batch, a.p) == ("ghp882", "64,16,16,16,16,16", 5000, 0.05)
+    a = bench.parse_args(["--config", "n1270_3r"])
+    assert (a.code, a.iters, a.batch, a.p) == ("ghp1270", "64,16,16,16", 5000, 0.07)
     a = bench.parse_args(["--config", "c2"])  # configs[1]: BP4-64 alone
     assert (a.code, a.iters, a.batch, a.p) == ("ghp882", "64", 65536, 0.01)
     a = bench.parse_args(["--config", "c4"])
@@ -101,6 +116,10 @@ def test_config_shapes_and_the_algorithmic_counts_of_the_other_two_configs():
     e1, l1 = bench.bp4_transcendentals_per_codeword(n, m, E, 1, False)
     assert (e1 - e0, l1 - l0) == (20 * n, 32 * n)       # literal form: one log-sum-exp per edge
     assert (e0, l0) == (4 * n + E + m, 4 * n + 2 * (E + m))  # cal_logit
+    e1, l1 = bench.bp4_transcendentals_per_codeword(n, m, E, 1, True, "boxplus")
+    assert (e1 - e0, l1 - l0) == (4 * n, 4 * n + E)      # 'boxplus': the tanh is a rational, the atanh one log1p per edge (decoding_q.py:313-363)
+    e1, l1 = bench.bp4_transcendentals_per_codeword(n, m, E, 1, True, "minsum")
+    assert (e1 - e0, l1 - l0) == (4 * n, 4 * n)
     assert abs(bench.HW_TRANSCENDENTAL_PEAK - 1.966e13) < 1e10
     n, m, E = 1270, 1270, 7620
     per_it = bench.gnnbp4_flops_per_codeword(n, m, E, 2) - bench.gnnbp4_flops_per_codeword(n, m, E, 1)
@@ -154,18 +173,26 @@ def test_bench_lines_of_the_bp4_only_configs():
     applies and --require-roofline passes) and `--config c2` (configs[1]: BP4-64 alone; here at a batch without an entry): one decoder
     launch per step, no feedback-GNN object in the roofline, the literal-forms leg and the per-sample agreement like the headline."""
     import bench
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c1", "--steps", "4", "--warmup", "1", "--cpu-sample", "32",
-                          "--no-extras", "--require-roofline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
-    d = json.loads([l for l in res.stdout.splitlines() if l.strip()][0])
-    r = d["roofline"]
-    ent, _ = bench.pmc_entry("bp4", "bp4_ghp882_it32_B256")
-    assert res.returncode == (0 if ent else 5), res.stderr[-2000:]
-    assert d["metric"] == "decoded codewords/sec, [[882,24]] BP4 32 iters" and "configs[0]" in d["config"]["workload"]
-    assert d["config"]["bp_iters"] == [32] and d["config"]["p"] == 0.05 and d["config"]["batch_per_gpu"] == 256
-    assert r["gnn"] is None and r["launches_timed"] == 4 and r["later_decoders_avg_launch_ms"] is None
-    assert (r["frac"] is not None and 0 < r["frac"] <= 1) if ent else r["frac"] is None
-    assert d["cpu_baseline"]["gpu_matches_oracle_bit_exact"] is True and d["forms_agreement"]["samples"] == 256
-    assert d["counts"]["samples"] == 4 * 256 and d["literal_forms"]["value"] > 0
+    for extra, key, cn in (([], "bp4_ghp882_it32_B256_boxplus", "boxplus"), (["--cn-type", "boxplus-phi"], "bp4_ghp882_it32_B256", "boxplus-phi")):
+        # configs[0] as the reference constructs it (cn_type='boxplus', normalization_factor=0.625: decoding_q.py:18-22), then the
+        # QLDPC.ipynb cell 11 helper's 'boxplus-phi' variant of the same case
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c1", "--steps", "4", "--warmup", "1", "--cpu-sample", "32",
+                              "--no-extras", "--require-roofline"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+        d = json.loads([l for l in res.stdout.splitlines() if l.strip()][0])
+        r = d["roofline"]
+        ent, _ = bench.pmc_entry("bp4", key)
+        assert res.returncode == (0 if ent else 5), res.stderr[-2000:]
+        assert d["metric"] == "decoded codewords/sec, [[882,24]] BP4 32 iters" and "configs[0]" in d["config"]["workload"]
+        assert d["config"]["bp_iters"] == [32] and d["config"]["p"] == 0.05 and d["config"]["batch_per_gpu"] == 256
+        assert d["config"]["cn_type"] == cn and d["config"]["normalization_factor"] == 0.625 and f"cn_type={cn}" in d["config"]["workload"]
+        assert f"bp4_kernel<{cn}>" in r["kernel"]
+        assert r["gnn"] is None and r["launches_timed"] == 4 and r["later_decoders_avg_launch_ms"] is None
+        assert (r["frac"] is not None and 0 < r["frac"] <= 1) if ent else r["frac"] is None
+        assert d["cpu_baseline"]["gpu_matches_oracle_bit_exact"] is True and d["forms_agreement"]["samples"] == 256
+        assert d["forms_agreement"]["p"] == 0.05  # the agreement of the default forms with the literal ones at the configuration's own p
+        assert d["cpu_baseline_tf_like"]["value"] > 0
+        assert d["counts"]["samples"] == 4 * 256 and d["literal_forms"]["value"] > 0
+        assert d["dist"]["world_size"] == 1 and d["dist"]["ranks"][0]["device_index"] == 0 and "value_is" in d
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c2", "--steps", "2", "--warmup", "1", "--batch", "2048",
                           "--cpu-sample", "32", "--no-extras", "--no-build"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                          timeout=900, cwd=ROOT)
@@ -173,6 +200,27 @@ def test_bench_lines_of_the_bp4_only_configs():
     d = json.loads([l for l in res.stdout.splitlines() if l.strip()][0])
     assert d["metric"] == "decoded codewords/sec, [[882,24]] BP4 64 iters" and "BP4-64 alone" in d["config"]["workload"]
     assert d["roofline"]["gnn"] is None and d["roofline"]["frac"] is None and d["forms_agreement"]["decisions_differ"] == 0
+    assert d["cpu_baseline"]["gpu_matches_oracle_bit_exact"] is True
+
+
+@pytest.mark.gpu
+def test_bench_line_of_a_published_workload():
+    """`--config n882_3r`: the workload of the reference's published 10.9 k codewords/s (examples/n882.ipynb cell 2: (64, G, 16, G, 16, G,
+    16), batch_size 5 000, p = 0.05, n882.py:39,56-66) — one stream and two streams timed in the same run, literal forms and the
+    per-sample agreement at p = 0.05, GPU == oracle on the sampled codewords."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "n882_3r", "--steps", "3", "--warmup", "1", "--cpu-sample", "32",
+                          "--no-extras"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.strip()][0])
+    assert d["config"]["bp_iters"] == [64, 16, 16, 16] and d["config"]["batch_per_gpu"] == 5000 and d["config"]["p"] == 0.05
+    assert "3 x (feedback-GNN + BP4-16)" in d["metric"] and "n882.ipynb" in d["config"]["workload"] and d["vs_baseline"] is None
+    assert d["counts"]["samples"] == 3 * 5000 and d["config"]["streams"] == 1
+    t = d["two_streams"]
+    assert t["streams"] == 2 and t["value"] > 0 and abs(t["value"] - 3 * 5000 / (t["ms_per_step"] * 3e-3)) < 1e-6 * t["value"]
+    assert d["literal_forms"]["value"] > 0 and d["forms_agreement"]["samples"] == 5000 and d["forms_agreement"]["p"] == 0.05
+    r = d["roofline"]
+    assert r["launches_timed"] == 3 and r["later_decoders_avg_launch_ms"] > 0 and r["gnn"]["launches_timed"] == 9
+    assert "streaming VALU" in r["gnn"]["kernel"] and d["config"]["gnn_kernel"] == "streaming VALU"  # 5 000 >= 4 096 codewords
     assert d["cpu_baseline"]["gpu_matches_oracle_bit_exact"] is True
 
 
@@ -273,6 +321,13 @@ def test_bench_three_ranks_equal_one_process_over_the_same_global_samples():
     assert len(d["per_rank_ms"]) == N and abs(max(d["per_rank_ms"]) - d["ms_per_step"]) < 1e-6 * d["ms_per_step"]
     assert abs(d["value"] - 2 * N * Bq / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d  # the CPU legs belong to the single-GPU line
+    # the pre-flight map (n882.py:9-25: one process per GPU id): world size and backend as torch.distributed reports them, one row per
+    # rank gathered by all-gather — here three ranks share cuda:0 over gloo, which the line must SAY (under RCCL that is exit code 7)
+    ds = d["dist"]
+    assert ds["world_size"] == N and ds["backend"] == "gloo" and [r["rank"] for r in ds["ranks"]] == [0, 1, 2]
+    assert [r["local_rank"] for r in ds["ranks"]] == [0, 1, 2] and {r["device_index"] for r in ds["ranks"]} == {0}
+    assert len({r["pid"] for r in ds["ranks"]}) == N and all("MI3" in r["device_name"] or r["device_name"] for r in ds["ranks"])
+    assert ds["one_distinct_device_per_rank"] is False
     res1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", str(N * Bq),
                            "--p", "0.1", "--cpu-sample", "0", "--no-extras", "--no-build"], stdout=subprocess.PIPE,
                           stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)

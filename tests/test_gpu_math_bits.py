@@ -90,7 +90,7 @@ def test_shared_math_against_float64_libm_exhaustively():
 
 @pytest.mark.gpu
 def test_device_math_bits_equal_the_gcc_build_exhaustively():
-    """hipcc/gfx950 bits == gcc/x86 bits for every input of every routine's domain (about 5.0e10 evaluations per side)."""
+    """hipcc/gfx950 bits == gcc/x86 bits for every input of every routine's domain (4.73e10 evaluations per side)."""
     import __graft_entry__ as entry
     exe = entry.build_math_bits_exhaustive()
     out = os.path.join(os.path.dirname(exe), "math_bits.bin")
@@ -110,7 +110,7 @@ def test_device_math_bits_equal_the_gcc_build_exhaustively():
                       + ("device == gcc" if not bad.size else f"{bad.size} windows differ, first window starts at bits 0x{first:08x}"))
         assert not bad.size, "\n".join(report)
         total += hi - lo + 1
-    assert pos == dev.shape[0] and total > 4.9e10
+    assert pos == dev.shape[0] and total > 4.7e10
     rep = os.environ.get("FGNN_MATH_BITS_REPORT")
     if rep:
         open(rep, "w").write("\n".join(report) + f"\ntotal {total} inputs per side, window = 2^{CHUNK_LOG2} bit patterns, "

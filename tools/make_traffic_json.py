@@ -75,7 +75,8 @@ for spec in sys.argv[2:]:
     if what == "merge":
         out.update(json.load(open(path)))
         continue
-    kind, code, B, iters = what.split(":")
+    kind, code, B, iters, *cn = what.split(":")  # optional fifth field: the check-node rule when it is not 'boxplus-phi' (bench.py's key suffix)
+    suffix = f"_{cn[0]}" if cn and cn[0] != "boxplus-phi" else ""
     rows = read_rows(path)
     if kind == "sandwich":
         # the FIRST decoder's launch (constant channel LLR: template argument NQ = 0) — the later decoders of a sandwich carry
@@ -83,7 +84,7 @@ for spec in sys.argv[2:]:
         bp = pick(rows, "bp4_kernel", lambda nm: re.search(r",\s*0,\s*false>$", nm) is not None)
         if bp:
             (name, wg), v = bp
-            out[f"bp4_{code}_it{iters}_B{B}"] = entry("bp4", name, v)
+            out[f"bp4_{code}_it{iters}_B{B}{suffix}"] = entry("bp4", name, v)
         gn = pick(rows, "gnn_stream_kernel") or pick(rows, "gnn_mfma_kernel")  # the streaming VALU kernel is the default of the factored order
         if gn:
             (name, wg), v = gn

@@ -1,5 +1,5 @@
 """Launch each hot kernel a few times at the benchmark shape (for rocprofv3 --kernel-trace / --pmc passes).
-    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU ... -d out -- python3 tools/prof_kernels.py [code] [B] [fixed|product] [iters, e.g. 64,16] [p]
+    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU ... -d out -- python3 tools/prof_kernels.py [code] [B] [fixed|product] [iters, e.g. 64,16] [p] [cn_type] [factor]
 One iteration count (e.g. 32) = the BP4 launch alone (BASELINE configs[0] / [1]).  `fixed` (default) switches the exact shortcuts off, like bench.py's headline: every exp/log of every iteration is evaluated."""
 import sys
 import torch
@@ -18,16 +18,18 @@ if os.environ.get("FGNN_BENCH_BP4_LSE"):
 if os.environ.get("FGNN_BENCH_GNN_ORDER"):  # "literal" / "factored": the same switch as bench.py (default: the library's)
     g.set_gnn_factored(os.environ["FGNN_BENCH_GNN_ORDER"] != "literal")
 P = float(sys.argv[5]) if len(sys.argv) > 5 else 0.01
+CN = sys.argv[6] if len(sys.argv) > 6 else "boxplus-phi"
+FACTOR = float(sys.argv[7]) if len(sys.argv) > 7 else 1.0
 ex, ez = g.pauli_noise(0x5EED, P, 0, B)
 sx, sz = g.syndrome(ex, ez)
 L0 = llr_const(0.05)
 w = GnnWeights(read_weight_list(WEIGHTS_882 if name == 'ghp882' else WEIGHTS_1270), g.device)
 for _ in range(2):
-    o = g.bp4_decode(sx, sz, ITERS[0], "boxplus-phi", 1.0, llr_const=L0)
+    o = g.bp4_decode(sx, sz, ITERS[0], CN, FACTOR, llr_const=L0)
     if len(ITERS) == 1:
         continue
     nl = g.feedback_gnn(w, o['llr'], o['z_logit'], o['x_logit'], sx, sz)
-    o2 = g.bp4_decode(sx, sz, ITERS[1], "boxplus-phi", 1.0, llr_ch=nl)
+    o2 = g.bp4_decode(sx, sz, ITERS[1], CN, FACTOR, llr_ch=nl)
     g.residual(ex, ez, o2['x_hat'], o2['z_hat'])
 torch.cuda.synchronize()
 print("done")
