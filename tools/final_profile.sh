@@ -1,24 +1,42 @@
 #!/bin/bash
-# One gpurun call that produces everything profiles/ cites for a round:  bash tools/final_profile.sh <tag>
+# Everything profiles/ cites for a round, in phases that each fit one gpurun call (20 minutes):
+#     bash tools/final_profile.sh <tag> tests counts        then        bash tools/final_profile.sh <tag> lines traces
 # (GPU tests; the PMC passes of the BASELINE configurations -> traffic.json; the five bench lines; a rocprofv3 kernel trace of the
 # same bench commands; the batch-size table).  Copy what is to be judged from gpurun_out/<tag>/ into profiles/ afterwards.
 set -e
 TAG=${1:-r00}
+shift || true
+PHASES=${@:-tests counts lines traces}
+has() { [[ " $PHASES " == *" $1 "* ]]; }
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
+if has tests; then
 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1 || { tail -30 $O/pytest_gpu.log; exit 1; }
 tail -2 $O/pytest_gpu.log
+fi
+if has counts; then
 # counts first: the bench lines below then quote THIS library's PMC passes (library_is_the_profiled_binary: true)
-bash tools/refresh_traffic.sh $TAG c1 c3 c4 c5 > $O/refresh.log 2>&1
+bash tools/refresh_traffic.sh $TAG c1 c1phi c3 c4 c5 n882 n1270 > $O/refresh.log 2>&1
 cp $O/traffic.json profiles/traffic.json
+fi
+if has lines; then
 python bench.py --no-build --require-roofline > $O/bench_c3.json 2> $O/bench.err
 python bench.py --no-build --config c4 --require-roofline > $O/bench_c4.json 2>> $O/bench.err
 python bench.py --no-build --config c5 --require-roofline > $O/bench_c5.json 2>> $O/bench.err
-python bench.py --no-build --config c1 --require-roofline > $O/bench_c1.json 2>> $O/bench.err
+# configs[0] as the reference constructs it (cn_type='boxplus', normalization_factor=0.625) and the QLDPC.ipynb cell 11 variant ('boxplus-phi')
+python bench.py --no-build --config c1 --steps 50 --warmup 5 --require-roofline > $O/bench_c1_boxplus.json 2>> $O/bench.err
+python bench.py --no-build --config c1 --cn-type boxplus-phi --steps 50 --warmup 5 --require-roofline > $O/bench_c1_boxplus_phi.json 2>> $O/bench.err
 python bench.py --no-build --config c2 --require-roofline > $O/bench_c2.json 2>> $O/bench.err
+# the workloads of the reference's published timings: batch_size 5 000, one and two streams in the same run
+python bench.py --no-build --config n882_3r --steps 100 --warmup 5 --require-roofline > $O/bench_n882_3r.json 2>> $O/bench.err
+python bench.py --no-build --config n882_5r --steps 100 --warmup 5 --require-roofline > $O/bench_n882_5r.json 2>> $O/bench.err
+python bench.py --no-build --config n1270_3r --steps 100 --warmup 5 --require-roofline > $O/bench_n1270_3r.json 2>> $O/bench.err
 cat $O/bench_c3.json
+echo "bench stderr:"; cat $O/bench.err || true
+fi
+if has traces; then
 # kernel traces of the same commands (no CPU legs, no extras, --no-literal: only the launches of the warm-up and of the timed region —
 # the literal-forms launches are the same BP4 symbol with a runtime flag and would be averaged into its statistics)
 for cfg in c3 c4 c5; do
@@ -29,4 +47,5 @@ done
 cat $O/dispatches_c3.txt
 python tools/batch_size_table.py $O/batch_sizes.json > $O/batch_sizes.txt 2>&1 || true
 python tools/harness_rate.py 0.05 3 40 2>&1 | grep "^(" > $O/harness_rate.txt || true
+fi
 grep -E "(bp4_kernel|gnn_stream_kernel|gnn_bp4).* (FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU |SQ_INSTS_MFMA|GRBM_GUI_ACTIVE)" $O/c*_pmc_summary.txt || true
