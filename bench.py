@@ -8,6 +8,13 @@
   c3  configs[2]  [[882,24]]  sandwich BP4-64 + feedback GNN + BP4-16, 65 536 codewords per GPU and step (n882.py:45-66) — the headline
   c4  configs[3]  [[1270,28]] sandwich BP4-64 + feedback GNN + BP4-64, 262 144 / 8 = 32 768 codewords per GPU and step (n1270.py:37,57)
   c5  configs[4]  [[1270,28]] GNN_BP4, 10 iterations, seeded weights, 131 072 / 8 = 16 384 codewords per GPU and step (gnn.py:383-423)
+  c1  configs[0]  [[882,24]]  BP4-32 alone, 256 codewords, p = 0.05, AS THE REFERENCE CONSTRUCTS IT: cn_type='boxplus', normalization_factor
+                  0.625 (decoding_q.py:18-22); `--cn-type boxplus-phi` is the QLDPC.ipynb cell 11 helper's variant.  A latency figure.
+  c2  configs[1]  [[882,24]]  BP4-64 alone, 65 536 codewords (the first launch of c3)
+  n882_3r / n882_5r / n1270_3r   the workloads of the reference's only published timings (one RTX 4090, TF-XLA):
+                  (64, G, 16) x 3 or 5 feedback rounds, batch_size 5 000, p = 0.05 / 0.07 (n882.py:13,39,56-66, n1270.py:57-70); timed on one
+                  stream (`value`) and with consecutive batches alternating between two HIP streams (`two_streams`) in the same run.
+`--cn-type` / `--factor` set the check-node rule and normalization factor of every decoder (default: the configuration's).
 
 One "step" = one Monte-Carlo batch through the whole hot path, everything on device: Philox depolarizing noise -> syndromes -> decoder
 (c3 / c4: BP4 -> flag update -> feedback GNN (trained weights) -> BP4 -> masked merge; c5: GNN_BP4) -> residual check -> counters, at
@@ -43,11 +50,15 @@ streaming dataflow: 16E+12n+4m bytes per codeword-iteration + 4E+24n+2n+4m epilo
 that exceeds 1 because the messages never travel; `hbm_frac` = measured HBM bytes (`traffic`, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE) /
 launch time / 8 TB/s.  `roofline.gnn` prices the feedback-GNN launch the same way.
 
+`dist` is the multi-GPU pre-flight: world size and backend as torch.distributed reports them and one row per rank (LOCAL_RANK -> device
+index, name, uuid, pid) gathered by all-gather; a rank that is not on cuda:LOCAL_RANK under RCCL exits 6, ranks sharing a device exit 7.
+
 `cpu_baseline` times the oracle (a C port of the reference arithmetic, OpenMP over codewords) on the host cores on a bounded sample of
 the same workload; `cpu_baseline_tf_like` times an op-for-op restatement of how the reference executes on a host (batch-minor [E,B]
 tensors, one framework op at a time: oracle/torch_cpu_baseline.py; c5: the batched-matmul NumPy restatement oracle/numpy_ref.py) —
-TensorFlow itself can run on neither box.  Both CPU legs run BEFORE the GPU is touched, so the tail of the process is continuous GPU
-work; the GPU's decisions on the sampled codewords are then checked against the oracle's bit for bit.
+TensorFlow itself can run on neither box.  Both CPU legs run BEFORE the GPU is touched, in a child interpreter whose thread pools end with
+it; a 0.25 s settle phase of dummy decodes precedes the W warm-up steps; the GPU's decisions on the sampled codewords are then checked
+against the oracle's bit for bit.
 """
 import argparse
 import json
@@ -167,7 +178,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS),
                     help="BASELINE.json configuration: c3 = configs[2] (headline), c4 = configs[3] shard, c5 = configs[4] shard (GNN_BP4); "
-                         "c1 = configs[0] (BP4-32, 256 codewords, p = 0.05), c2 = configs[1] (BP4-64 alone)")
+                         "c1 = configs[0] (BP4-32, 256 codewords, p = 0.05, 'boxplus' 0.625), c2 = configs[1] (BP4-64 alone); n882_3r / n882_5r / "
+                         "n1270_3r = the workloads of the reference's published timings (batch 5 000)")
     ap.add_argument("--batch", type=int, default=None, help="codewords per GPU per step (default: the configuration's)")
     ap.add_argument("--p", type=float, default=None, help="depolarizing probability (default: the configuration's, 0.01 unless it names one)")
     ap.add_argument("--code", default=None, choices=["ghp882", "ghp1270"], help="default: the configuration's")
