@@ -716,6 +716,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args, sys.argv[1:])
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL on this pool (before any GPU runtime loads); a caller's setting wins
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
