@@ -40,7 +40,7 @@ if has traces; then
 # kernel traces of the same commands (no CPU legs, no extras, --no-literal: only the launches of the warm-up and of the timed region —
 # the literal-forms launches are the same BP4 symbol with a runtime flag and would be averaged into its statistics)
 for cfg in c3 c4 c5; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$cfg -- python3 bench.py --config $cfg --steps 3 --warmup 1 --cpu-sample 0 --no-extras --no-literal --no-build > $O/trace_bench_$cfg.json 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$cfg -- python3 bench.py --config $cfg --steps 8 --warmup 2 --cpu-sample 0 --no-extras --no-literal --no-build > $O/trace_bench_$cfg.json 2>&1
   python tools/dispatch_summary.py $O/trace_$cfg/*/*_kernel_trace.csv > $O/dispatches_$cfg.txt
   cp $O/trace_$cfg/*/*_kernel_stats.csv $O/kernel_stats_$cfg.csv
 done
