@@ -1407,7 +1407,9 @@ int og_osd0(const og_graph* g, int side, int rank, const int32_t* pivot_rows, co
 
 /* elementwise wrappers so tests can probe the shared math from Python.  Function ids (tests/math_bits_exhaustive.hip uses the same
  * numbering on the device): 0 exp, 1 log, 2 log1p, 3 softplus, 4 phi, 5 tanh, 6 atanh, 7 phi_gnn, 8 lse2_corr(x, 0), 9 sigmoid,
- * 10 div3, 11 rcp_unit, 12 div_atanh, 13 lse2(x, 1) */
+ * 10 div3, 11 rcp_unit, 12 div_atanh, 13 lse2(x, 1); integer-valued probes of fgnn_rng.h (og_math_bits only): 14 a Philox4x32-10 block
+ * keyed and countered by the input word, folded to one word, 15 fg_u32_to_unit, 16 the three Pauli thresholds of p = the input float,
+ * folded */
 static inline float og_math_fn(int fn, float v)
 {
     switch (fn) {
@@ -1427,6 +1429,24 @@ static inline float og_math_fn(int fn, float v)
     case 13: return fg_lse2(v, 1.0f);
     default: return 0.0f;
     }
+}
+
+static inline uint32_t og_rotl(uint32_t v, int r) { return (v << r) | (v >> (32 - r)); }
+
+/* result BITS of probe `fn` on the input bit pattern u (the function the exhaustive checksums are taken of) */
+static inline uint32_t og_math_bits(int fn, uint32_t u)
+{
+    if (fn == 14) {
+        uint32_t r[4];
+        fg_philox4x32_10(u, ~u, u * 2654435761u, u >> 3, 0x5EEDu ^ (u << 5), u >> 7, r);
+        return r[0] ^ og_rotl(r[1], 8) ^ og_rotl(r[2], 16) ^ og_rotl(r[3], 24);
+    }
+    if (fn == 15) return fg_f2u(fg_u32_to_unit(u));
+    if (fn == 16) {
+        const fg_pauli_thr t = fg_pauli_thresholds(fg_u2f(u));
+        return fg_f2u(t.px) ^ og_rotl(fg_f2u(t.lo), 8) ^ og_rotl(fg_f2u(t.hi), 16);
+    }
+    return fg_f2u(og_math_fn(fn, fg_u2f(u)));
 }
 
 void og_math_apply(int fn, const float* x, float* y, long nelem)
@@ -1471,7 +1491,7 @@ void og_math_checksums(int fn, uint32_t lo, uint32_t hi, int chunk_log2, uint64_
         double lw = -1.0;
         uint32_t lx = (uint32_t)a;
         for (uint64_t u = a; u <= b; ++u) {
-            const uint32_t y = fg_f2u(og_math_fn(fn, fg_u2f((uint32_t)u)));
+            const uint32_t y = og_math_bits(fn, (uint32_t)u);
             s1 += y;
             s2 += (uint64_t)y * (uint64_t)((uint32_t)u | 1u);
             if (max_ulp) {

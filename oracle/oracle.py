@@ -109,7 +109,10 @@ def philox(ctr, key):
 
 
 MATH_FUNCTIONS = {"exp": 0, "log": 1, "log1p": 2, "softplus": 3, "phi": 4, "tanh": 5, "atanh": 6, "phi_gnn": 7, "lse2_corr": 8,
-                  "sigmoid": 9, "div3": 10, "rcp_unit": 11, "div_atanh": 12, "lse2_1": 13}
+                  "sigmoid": 9, "div3": 10, "rcp_unit": 11, "div_atanh": 12, "lse2_1": 13,
+                  # integer-valued probes of fgnn_rng.h (checksums only, not math_apply): a Philox4x32-10 block, the uint32 -> [0,1) map,
+                  # the depolarizing thresholds of p
+                  "philox": 14, "u32_to_unit": 15, "pauli_thr": 16}
 
 
 def math_apply(name, x):

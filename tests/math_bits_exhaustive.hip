@@ -1,4 +1,4 @@
-// tests/math_bits_exhaustive.hip — the hipcc / gfx950 half of the exhaustive bit comparison of feedback_gnn_amd/csrc/fgnn_math.h.
+// tests/math_bits_exhaustive.hip — the hipcc / gfx950 half of the exhaustive bit comparison of feedback_gnn_amd/csrc/fgnn_math.h and fgnn_rng.h.
 //
 // The oracle (gcc, x86) and the kernels (hipcc, gfx950) compile the SAME header, so "HIP == oracle" on decoder outputs cannot see
 // a place where the two compilers, or the device paths of the header (FG_CLAMP = v_med3_f32, the rcp-based divisions, the LDS log
@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../feedback_gnn_amd/csrc/fgnn_math.h"
+#include "../feedback_gnn_amd/csrc/fgnn_rng.h"
 
 // same numbering as og_math_fn (oracle/fgnn_oracle.c)
 static __device__ __forceinline__ float apply(int fn, float v)
@@ -40,6 +41,36 @@ static __device__ __forceinline__ float apply(int fn, float v)
     }
 }
 
+// result bits of probe FN on input bits u; ids >= 14 are the integer-valued probes of fgnn_rng.h (same folding as og_math_bits)
+static __device__ __forceinline__ uint32_t rotl(uint32_t v, int r) { return (v << r) | (v >> (32 - r)); }
+static __device__ __forceinline__ uint32_t apply_bits(int fn, uint32_t u)
+{
+    if (fn == 14) {
+        uint32_t r[4];
+        fg_philox4x32_10(u, ~u, u * 2654435761u, u >> 3, 0x5EEDu ^ (u << 5), u >> 7, r);
+        return r[0] ^ rotl(r[1], 8) ^ rotl(r[2], 16) ^ rotl(r[3], 24);
+    }
+    if (fn == 15) return fg_f2u(fg_u32_to_unit(u));
+    if (fn == 16) {
+        const fg_pauli_thr t = fg_pauli_thresholds(fg_u2f(u));
+        return fg_f2u(t.px) ^ rotl(fg_f2u(t.lo), 8) ^ rotl(fg_f2u(t.hi), 16);
+    }
+    return fg_f2u(apply(fn, fg_u2f(u)));
+}
+
+// Random123 known-answer vectors for philox4x32-10, evaluated on the device
+__global__ void philox_kat(uint32_t* out)
+{
+    const uint32_t ctr[3][4] = {{0, 0, 0, 0}, {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, {0x243f6a88u, 0x85a308d3u, 0x13198a2eu, 0x03707344u}};
+    const uint32_t key[3][2] = {{0, 0}, {0xffffffffu, 0xffffffffu}, {0xa4093822u, 0x299f31d0u}};
+    if (threadIdx.x < 3) {
+        uint32_t r[4];
+        const int i = threadIdx.x;
+        fg_philox4x32_10(ctr[i][0], ctr[i][1], ctr[i][2], ctr[i][3], key[i][0], key[i][1], r);
+        for (int j = 0; j < 4; ++j) out[4 * i + j] = r[j];
+    }
+}
+
 constexpr int SPAN_LOG2 = 16;  // one workgroup walks 2^16 consecutive bit patterns, aligned: it lies inside one window (chunk_log2 >= 16)
 
 template <int FN>
@@ -51,7 +82,7 @@ __global__ void __launch_bounds__(256) sums(uint32_t lo, uint32_t hi, int chunk_
     for (int it = 0; it < (1 << SPAN_LOG2) / 256; ++it) {
         const uint64_t u = base + (uint64_t)it * 256 + threadIdx.x;
         if (u < lo || u > hi) continue;
-        const uint32_t y = fg_f2u(apply(FN, fg_u2f((uint32_t)u)));
+        const uint32_t y = apply_bits(FN, (uint32_t)u);
         s1 += y;
         s2 += (unsigned long long)y * (unsigned long long)((uint32_t)u | 1u);
     }
@@ -74,7 +105,7 @@ __global__ void __launch_bounds__(256) sums(uint32_t lo, uint32_t hi, int chunk_
 }
 
 typedef void (*kern_t)(uint32_t, uint32_t, int, unsigned long long*);
-static const kern_t KERNELS[] = {sums<0>, sums<1>, sums<2>, sums<3>, sums<4>, sums<5>, sums<6>, sums<7>, sums<8>, sums<9>, sums<10>, sums<11>, sums<12>, sums<13>};
+static const kern_t KERNELS[] = {sums<0>, sums<1>, sums<2>, sums<3>, sums<4>, sums<5>, sums<6>, sums<7>, sums<8>, sums<9>, sums<10>, sums<11>, sums<12>, sums<13>, sums<14>, sums<15>, sums<16>};
 
 int main(int argc, char** argv)
 {
@@ -89,6 +120,15 @@ int main(int argc, char** argv)
     }
     FILE* f = std::fopen(argv[1], "wb");
     if (!f) return 2;
+    {   // the device's Philox4x32-10 on the Random123 known-answer inputs, printed for the test to compare
+        uint32_t* d_kat;
+        uint32_t h_kat[12];
+        if (hipMalloc(&d_kat, sizeof(h_kat)) != hipSuccess) return 3;
+        hipLaunchKernelGGL(philox_kat, dim3(1), dim3(64), 0, 0, d_kat);
+        if (hipMemcpy(h_kat, d_kat, sizeof(h_kat), hipMemcpyDeviceToHost) != hipSuccess) return 3;
+        (void)hipFree(d_kat);
+        for (int i = 0; i < 3; ++i) std::printf("philox_kat %d: %08x %08x %08x %08x\n", i, h_kat[4 * i], h_kat[4 * i + 1], h_kat[4 * i + 2], h_kat[4 * i + 3]);
+    }
     for (int a = 3; a < argc; ++a) {
         unsigned fn;
         unsigned long long lo, hi;

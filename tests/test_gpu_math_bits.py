@@ -7,7 +7,7 @@ input BP never visits.  Two tests close that:
   (a) `test_shared_math_against_float64_libm_exhaustively` (CPU): every elementary routine against double-precision libm over every
       float32 of the domain it is used on, with the worst error in ulps bounded — a wrong coefficient, table entry or threshold
       shows up as thousands of ulps;
-  (b) `test_device_math_bits_equal_the_gcc_build_exhaustively` (GPU): for all 14 routines the bits the device build returns equal
+  (b) `test_device_math_bits_equal_the_gcc_build_exhaustively` (GPU): for all 14 routines (and three probes of fgnn_rng.h: Philox, the uint32 -> [0,1) map, the channel thresholds) the bits the device build returns equal
       the bits the gcc build returns for EVERY input of the domain (up to 2^32 - 2^24 floats each), compared through per-window
       checksums (tests/math_bits_exhaustive.hip on the device, og_math_checksums in the oracle).
 
@@ -38,7 +38,12 @@ DOMAINS = {
     "lse2_1": [POS, NEG],                                           # fg_lse2(x, 1): with the max term
     "div3": [POS, NEG], "rcp_unit": [POS, NEG],
     "div_atanh": [(0, 0x3f7ffffe)],
+    # fgnn_rng.h, shared the same way: a Philox4x32-10 block keyed and countered by the input word (all 2^32 words), the uint32 -> [0,1)
+    # map, and the float32 depolarizing thresholds of every p in [0, 1] (pauli.py:100-108 with px = pz = 2p/3, py = p/3)
+    "philox": [(0, 0xffffffff)], "u32_to_unit": [(0, 0xffffffff)], "pauli_thr": [(0, 0x3f800000)],
 }
+RNG_PROBES = ("philox", "u32_to_unit", "pauli_thr")
+PHILOX_KAT = ["6627e8d5 e169c58d bc57ac4c 9b00dbd8", "408f276d 41c83b0e a20bc7c6 6d5451fd", "d16cfe09 94fdcceb 5001e420 24126ea1"]  # Random123 kat_vectors
 CHUNK_LOG2 = 22
 
 
@@ -46,8 +51,11 @@ def test_checksum_probe_is_the_elementwise_function():
     """og_math_checksums (what both exhaustive tests stand on) = sums over og_math_apply's outputs, window by window."""
     lo, hi = 0x3f7ff000, 0x40801234  # straddles three 2^22 windows
     x = np.arange(lo, hi + 1, dtype=np.uint32)
-    for name in ("tanh", "phi", "log1p", "lse2_1"):
-        y = O.math_apply(name, x.view(np.float32)).view(np.uint32).astype(np.uint64)
+    for name in ("tanh", "phi", "log1p", "lse2_1", "u32_to_unit"):
+        if name == "u32_to_unit":  # an integer-valued probe: its own NumPy restatement (TensorFlow's Uint32ToFloat)
+            y = (((x >> 9) | np.uint32(0x3f800000)).view(np.float32) - np.float32(1.0)).view(np.uint32).astype(np.uint64)
+        else:
+            y = O.math_apply(name, x.view(np.float32)).view(np.uint32).astype(np.uint64)
         c = O.math_checksums(name, lo, hi, CHUNK_LOG2)
         win = (x >> CHUNK_LOG2) - (lo >> CHUNK_LOG2)
         assert c.shape == (int(win.max()) + 1, 2)
@@ -90,7 +98,7 @@ def test_shared_math_against_float64_libm_exhaustively():
 
 @pytest.mark.gpu
 def test_device_math_bits_equal_the_gcc_build_exhaustively():
-    """hipcc/gfx950 bits == gcc/x86 bits for every input of every routine's domain (4.73e10 evaluations per side)."""
+    """hipcc/gfx950 bits == gcc/x86 bits for every input of every routine's domain (5.7e10 evaluations per side), and the device's Philox4x32-10 on the Random123 known-answer vectors."""
     import __graft_entry__ as entry
     exe = entry.build_math_bits_exhaustive()
     out = os.path.join(os.path.dirname(exe), "math_bits.bin")
@@ -98,6 +106,8 @@ def test_device_math_bits_equal_the_gcc_build_exhaustively():
     args = [f"{O.MATH_FUNCTIONS[n]}:0x{lo:08x}:0x{hi:08x}" for n, lo, hi in jobs]
     res = subprocess.run([exe, out, str(CHUNK_LOG2)] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert res.returncode == 0, res.stdout
+    for i, kat in enumerate(PHILOX_KAT):  # the DEVICE's Philox on the Random123 known-answer inputs
+        assert f"philox_kat {i}: {kat}" in res.stdout, res.stdout
     dev = np.fromfile(out, dtype=np.uint64).reshape(-1, 2)
     pos, total, report = 0, 0, []
     for name, lo, hi in jobs:
@@ -110,7 +120,7 @@ def test_device_math_bits_equal_the_gcc_build_exhaustively():
                       + ("device == gcc" if not bad.size else f"{bad.size} windows differ, first window starts at bits 0x{first:08x}"))
         assert not bad.size, "\n".join(report)
         total += hi - lo + 1
-    assert pos == dev.shape[0] and total > 4.7e10
+    assert pos == dev.shape[0] and total > 5.6e10
     rep = os.environ.get("FGNN_MATH_BITS_REPORT")
     if rep:
         open(rep, "w").write("\n".join(report) + f"\ntotal {total} inputs per side, window = 2^{CHUNK_LOG2} bit patterns, "
