@@ -1035,6 +1035,16 @@ def main():
         else:
             out["literal_forms"] = {"value": value, "ms_per_step": elapsed / K * 1e3, "unit": "codewords/s",
                                     "what": "the headline of this run IS the literal forms (FGNN_BENCH_BP4_LSE / FGNN_BENCH_GNN_ORDER = literal)"}
+        if args.streams > 1 and not is_c5:
+            # launches of consecutive batches overlap on the chip, so a HIP-event bracket around one launch also covers its neighbour's
+            # work: the per-launch durations (and every fraction priced with them) are not this kernel's own — say so instead of quoting them
+            r = out["roofline"]
+            for k in ("frac", "achieved", "frac_of_hw_transcendental_rate", "effective_bandwidth_frac", "effective_bandwidth_GBs", "hbm_frac"):
+                r[k] = None
+            r["traffic_source"] = (f"--streams {args.streams}: per-launch HIP-event durations overlap between streams; the roofline fractions are "
+                                   "quoted for one-stream runs only")
+            if r.get("gnn"):
+                r["gnn"]["frac"] = r["gnn"]["achieved"] = None
         out.update(cpu_out)
         out["dist"] = dist_info
         if other_streams is not None:
