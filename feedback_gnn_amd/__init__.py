@@ -31,9 +31,9 @@ def __getattr__(name):
     if name in ("OSD0_Decoder", "BP4_OSD_Model", "BP2_OSD_Model"):
         from . import bp_osd as _o
         return getattr(_o, name)
-    if name == "GNN_BP4":
-        from .gnn import GNN_BP4
-        return GNN_BP4
+    if name in ("GNN_BP4", "MLP"):
+        from . import gnn as _gn
+        return getattr(_gn, name)
     if name in ("TannerGraph", "GnnWeights"):
         from . import graph as _g
         return getattr(_g, name)

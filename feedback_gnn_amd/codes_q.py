@@ -147,6 +147,13 @@ def _plaquette(n, i, j):
     return [i * n + j, i2 * n + j2, i2 * n + j, i * n + j2]
 
 
+def set_pcm_row(n, pcm, row_idx, i, j):
+    """Set, in row ``row_idx`` of ``pcm``, the four qubits of the plaquette with top-left corner (i, j) (codes_q.py:147-150 of the
+    reference: the helper its surface / toric constructions call; kept for scripts that build their own matrices with it)."""
+    for q in _plaquette(n, i, j):
+        pcm[row_idx][q] = 1
+
+
 def create_rotated_surface_codes(n, name=None):
     """[[n^2, 1, n]] rotated surface code, n odd: bulk plaquettes alternate Z (even i+j) / X, weight-2 X checks on the
     top (even columns) and bottom (odd columns) edge, weight-2 Z checks on the right (even rows) and left (odd rows) edge."""

@@ -14,6 +14,57 @@ import torch
 from .graph import ACTIVATIONS, REDUCE_OPS, GnnBp4Weights, TannerGraph, gnnbp4_weight_shapes
 
 
+class MLP:
+    """``MLP(units, activations, use_bias)`` — the reference's helper layer (gnn.py:25-69): a chain of Dense layers, built on the first
+    call from the input's last dimension (glorot-uniform kernels, ``bias_initializer='ones'``, gnn.py:55-60), ``layer(inputs)`` applies
+    it to the last axis.  A convenience for scripts that use the class on its own: it runs as torch ops on the input's device.  The
+    decoders do NOT go through it — the MLPs of `Feedback_GNN` and `GNN_BP4` are evaluated inside the HIP kernels from the same weight
+    arrays (``get_weights`` / ``set_weights`` use Keras' order: kernel, bias per layer)."""
+
+    _ACT = {"tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid, "linear": None, None: None}
+
+    def __init__(self, units, activations, use_bias, seed=0):
+        if not (len(units) == len(activations) == len(use_bias)):
+            raise ValueError("units, activations and use_bias must have one entry per layer")
+        for a in activations:
+            if a not in self._ACT:
+                raise NotImplementedError(f"activation {a!r}: tanh, relu, sigmoid and linear are implemented")
+        self._num_units, self._activations, self._use_bias = [int(u) for u in units], list(activations), [bool(b) for b in use_bias]
+        self._seed, self._weights = seed, None
+
+    def build(self, input_shape):
+        rng = np.random.RandomState(self._seed)
+        fan_in, w = int(input_shape[-1]), []
+        for units, bias in zip(self._num_units, self._use_bias):
+            lim = np.sqrt(6.0 / (fan_in + units))
+            w.append(rng.uniform(-lim, lim, size=(fan_in, units)).astype(np.float32))
+            if bias:
+                w.append(np.ones((units,), np.float32))
+            fan_in = units
+        self._weights = w
+
+    def get_weights(self):
+        return [a.copy() for a in (self._weights or [])]
+
+    def set_weights(self, weights):
+        self._weights = [np.asarray(a, dtype=np.float32) for a in weights]
+
+    def __call__(self, inputs):
+        x = torch.as_tensor(inputs, dtype=torch.float32)
+        if self._weights is None:
+            self.build(tuple(x.shape))
+        it = iter(torch.from_numpy(a).to(x.device) for a in self._weights)
+        for act, bias in zip(self._activations, self._use_bias):
+            x = x @ next(it)
+            if bias:
+                x = x + next(it)
+            if self._ACT[act] is not None:
+                x = self._ACT[act](x)
+        return x
+
+    call = __call__
+
+
 class GNN_BP4:
     """``decoder((syndrome_x[bs,m_x], syndrome_z[bs,m_z]))`` → ``(llr_hat, x_hat[n,bs], z_hat[n,bs])`` where ``llr_hat`` is a
     list with one ``(x_perp_logit[m_z+k,bs], z_perp_logit[m_x+k,bs])`` pair per iteration (gnn.py:409)."""

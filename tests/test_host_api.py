@@ -80,6 +80,34 @@ def test_public_names_mirror_the_reference():
                  "hypergraph_product", "create_rotated_surface_codes", "create_surface_codes", "hamming_code", "readAlist",
                  "sim_ber", "PlotBER", "count_block_errors", "int_mod_2"):
         assert hasattr(F, name), name
+    # every QLDPC-path name sionna/fec/ldpc/__init__.py:9-20 exports (the 5G names — LDPC5GEncoder / Decoder, AllZeroEncoder, `codes` —
+    # are the out-of-scope wireless stack)
+    for name in ("LDPCBPDecoder", "First_Stage_BP_Model", "Second_Stage_GNN_BP_Model", "BP_BSC_Model", "GNN_BP4", "MLP", "OSD0_Decoder",
+                 "BP4_OSD_Model", "BP2_OSD_Model", "create_checkerboard_toric_codes", "create_bivariate_QC_codes", "create_circulant_matrix",
+                 "rep_code", "set_pcm_row"):
+        assert hasattr(F, name), name
+
+
+def test_mlp_helper_layer_and_set_pcm_row():
+    """gnn.py:25-69: `MLP(units, activations, use_bias)` builds on the first call (glorot kernels, ones biases), applies the Dense chain to
+    the last axis, and exposes its arrays in Keras' order; codes_q.py:147-150: `set_pcm_row` marks the four qubits of a plaquette."""
+    m = F.MLP([40, 20], ["tanh", None], [True, False])
+    x = torch.from_numpy(np.random.RandomState(0).randn(3, 5, 4).astype(np.float32))
+    y = m(x)
+    w = m.get_weights()
+    assert [a.shape for a in w] == [(4, 40), (40,), (40, 20)] and np.all(w[1] == 1.0) and np.abs(w[0]).max() <= np.sqrt(6.0 / 44)
+    ref = np.tanh(x.numpy().astype(np.float64) @ w[0] + w[1]) @ w[2]
+    assert y.shape == (3, 5, 20) and np.abs(ref - y.numpy()).max() < 1e-5
+    m2 = F.MLP([40, 20], ["tanh", None], [True, False])
+    m2.set_weights(w)
+    assert torch.equal(m2(x), y)
+    with pytest.raises(ValueError):
+        F.MLP([4], ["tanh", "tanh"], [True])
+    with pytest.raises(NotImplementedError):
+        F.MLP([4], ["gelu"], [True])
+    pcm = np.zeros((2, 9), dtype=int)
+    F.set_pcm_row(3, pcm, 1, 2, 2)  # wraps around: (2,2), (0,0), (0,2), (2,0)
+    assert pcm[0].sum() == 0 and sorted(np.nonzero(pcm[1])[0]) == [0, 2, 6, 8]
 
 
 def test_count_block_errors_and_sim_ber_qldpc():
