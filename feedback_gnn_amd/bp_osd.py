@@ -10,12 +10,52 @@ from .feedback_gnn import Pauli
 
 
 class OSD0_Decoder:
-    """Order-0 ordered-statistics decoder (bp_osd.py:8-77).  The reference's `call(llr, pcm, s, bs)` takes the row
-    basis as a dense batched tensor; here the basis lives in the device graph (`fgnn_graph_set_basis`) and the
-    decoder is driven by `BP4_OSD_Model`."""
+    """Order-0 ordered-statistics decoder (bp_osd.py:8-77).  Inside `BP4_OSD_Model` / `BP2_OSD_Model` the row basis lives in the
+    model's device graph (`fgnn_graph_set_basis`) and only the BP failures are re-solved; the reference's standalone
+    ``decoder(llr, pcm, s, bs)`` is served by `__call__` below through the same HIP kernel (`fgnn_osd0`)."""
 
-    def __init__(self, n):
+    def __init__(self, n, device=None):
         self.n = int(n)
+        self._device = device
+        self._graphs = {}  # basis bytes -> device graph with the basis installed (a caller reuses one basis for every batch)
+
+    def _graph_of(self, basis):
+        from .decoding import _binary_graph
+        key = (basis.shape, basis.tobytes())
+        g = self._graphs.get(key)
+        if g is None:
+            g = _binary_graph(basis, None, self._device)
+            g.set_basis(0, np.arange(basis.shape[0], dtype=np.int32))
+            self._graphs = {key: g}
+        return g
+
+    def __call__(self, llr, pcm, s, bs=None):
+        """The reference's standalone call (bp_osd.py:47-77): ``llr [bs, n]`` binary reliabilities (sorted ascending: the least
+        reliable "no error" positions become the pivots), ``pcm [bs, rank, n]`` the FULL-RANK row basis tiled over the batch (the
+        reference's models tile one matrix, :147-150; this implementation requires that — or takes a plain ``[rank, n]`` matrix),
+        ``s [rank, bs]`` the syndrome of those rows → ``e_hat [bs, n]`` bool with ``pcm e_hat = s`` on the most reliable basis.
+        Ties in the sort keep qubit order (tf.argsort leaves them unspecified)."""
+        pcm_t = torch.as_tensor(pcm)
+        if pcm_t.dim() == 3:
+            if pcm_t.shape[0] > 1 and not bool((pcm_t == pcm_t[:1]).all()):
+                raise NotImplementedError("OSD0_Decoder: one row basis per call (the reference tiles the same matrix over the batch)")
+            pcm_t = pcm_t[0]
+        basis = np.ascontiguousarray(pcm_t.cpu().numpy() != 0, dtype=np.uint8)
+        if basis.shape[1] != self.n:
+            raise ValueError("pcm must have n columns")
+        g = self._graph_of(basis)
+        llr = torch.as_tensor(llr, device=g.device).to(torch.float32).contiguous()
+        B = int(llr.shape[0])
+        if bs is not None and int(bs) != B:
+            raise ValueError("bs must equal the leading dimension of llr")
+        synd = (torch.as_tensor(s, device=g.device).to(torch.int64) & 1).to(torch.uint8).t().contiguous()
+        if tuple(synd.shape) != (B, basis.shape[0]):
+            raise ValueError(f"s must have shape [{basis.shape[0]}, {B}]")
+        e_hat = torch.zeros((B, self.n), dtype=torch.uint8, device=g.device)
+        g.osd0(0, synd, e_hat, llr_bin=llr)
+        return e_hat.bool()
+
+    call = __call__
 
 
 class BP4_OSD_Model:

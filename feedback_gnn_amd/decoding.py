@@ -48,6 +48,42 @@ class LDPCBPDecoder:
         self._normalization_factor, self._is_syndrome, self._output_dtype = float(normalization_factor), bool(is_syndrome), output_dtype
         self.graph = graph if graph is not None else _binary_graph(pcm, None, device)
         self._num_vns, self._num_cns = self.graph.n, self.graph.m_x
+        self._pcm = pcm
+
+    # ---- the reference class' read-only surface (decoding.py:420-494) ----
+    pcm = property(lambda self: self._pcm)
+    num_cns = property(lambda self: self._num_cns)
+    num_vns = property(lambda self: self._num_vns)
+    num_edges = property(lambda self: int(self.graph.E_x))
+    has_weights = property(lambda self: False)     # trainable=True is refused by the constructor
+    output_dtype = property(lambda self: self._output_dtype)
+    llr_max = property(lambda self: 20.0)          # the input clip of decoding.py:918-920, fixed in the kernel (fgnn_bp2_decode)
+
+    @property
+    def num_iter(self):
+        return self._num_iter
+
+    @num_iter.setter
+    def num_iter(self, value):
+        if not isinstance(value, (int, np.integer)) or value < 0:
+            raise AssertionError('num_iter cannot be negative.')
+        self._num_iter = int(value)
+
+    @property
+    def edge_weights(self):
+        raise NotImplementedError("no trainable edge weights on the syndrome-decoding path (has_weights is False)")
+
+    @property
+    def ie_c(self):
+        raise NotImplementedError("EXIT tracking (track_exit) is not part of the syndrome-decoding path")
+
+    ie_v = ie_c
+
+    def show_weights(self, size=7):
+        raise NotImplementedError("no trainable edge weights on the syndrome-decoding path")
+
+    def build(self, input_shape=None):
+        """Keras builds lazily; this class is ready after construction."""
 
     def __call__(self, inputs):
         g = self.graph
@@ -70,6 +106,8 @@ class LDPCBPDecoder:
                                   want_soft=not self._hard_out, want_hard=self._hard_out)
         out = hard.to(self._output_dtype) if self._hard_out else soft.to(self._output_dtype)
         return out.reshape(shape)
+
+    call = __call__
 
 
 class BP_BSC_Model:

@@ -74,6 +74,27 @@ class QLDPCBPDecoder:
     def dtype(self):
         return self._output_dtype
 
+    def build(self, input_shape=None):
+        """Keras builds lazily (decoding_q.py:646-659 only validates shapes); this class is ready after construction."""
+
+    def show_weights(self, size=7):
+        raise NotImplementedError("no trainable edge weights: the reference's QLDPCBPDecoder never applies them either (SURVEY.md a10)")
+
+    def cal_logit(self, llrx, llry, llrz):
+        """Soft syndromes of given marginals (decoding_q.py:455-471): ``llrx, llry, llrz [n, bs]`` (the layout `call` holds them in)
+        → ``(x_perp_logit[rows_x, bs], z_perp_logit[rows_z, bs])``.  Evaluated by the decoder kernel's own epilogue: a zero-iteration
+        decode whose channel LLRs are the given marginals returns them unchanged together with their soft syndromes."""
+        g = self.graph
+        llr = torch.stack([torch.as_tensor(t, device=g.device).to(torch.float32) for t in (llrx, llry, llrz)], dim=0)  # [3, n, bs]
+        if llr.dim() != 3 or llr.shape[1] != self._num_vns:
+            raise ValueError('llrx, llry, llrz must have shape [n, batch_size].')
+        llr = llr.permute(2, 0, 1).contiguous()  # [bs, 3, n]
+        B = llr.shape[0]
+        sx = torch.zeros((B, self._num_cns_x), dtype=torch.uint8, device=g.device)
+        sz = torch.zeros((B, self._num_cns_z), dtype=torch.uint8, device=g.device)
+        out = g.bp4_decode(sx, sz, 0, self._cn_type, self._normalization_factor, llr_ch=llr, want_logits=True)
+        return out["x_logit"].t(), out["z_logit"].t()
+
     def _syndrome_in(self, s, rows):
         s = torch.as_tensor(s, device=self.graph.device)
         if s.dim() != 2 or s.shape[0] != rows:
@@ -124,3 +145,5 @@ class QLDPCBPDecoder:
         hat = torch.stack((out["x_logit"], out["z_logit"]), dim=1).reshape(2 * self._num_iter + 2, B, rows_x).transpose(1, 2)
         x_hat, z_hat = self._hard_out_dtypes(out["x_hat"], out["z_hat"])
         return hat, x_hat, z_hat
+
+    call = __call__

@@ -552,3 +552,81 @@ def test_mc_step_on_two_streams_counts_the_same_samples():
         res[streams] = (first.tolist(), counts.tolist(), ring.tolist(), direct)
     assert res[1][0][2] == steps * B and res[1][0][1] > 0
     assert res[2] == res[1] and res[3] == res[1], res
+
+
+def _numpy_osd0(llr, basis, synd):
+    """OSD-0 as bp_osd.py:14-77 states it, one sample: columns sorted by ascending llr (stable), Gauss-Jordan over GF(2) taking for
+    every row the first remaining column with a 1, solution on the pivot columns."""
+    order = np.argsort(llr, kind="stable")
+    a = np.concatenate([basis[:, order], synd[:, None]], axis=1).astype(np.uint8)
+    rank, n = basis.shape
+    piv = []
+    for r in range(rank):
+        c = int(np.argmax(a[r, :n]))
+        assert a[r, c] == 1, "basis must be full rank"
+        piv.append(c)
+        rows = np.nonzero(a[:, c])[0]
+        rows = rows[rows != r]
+        a[rows] ^= a[r]
+    e = np.zeros(n, np.uint8)
+    e[order[np.asarray(piv)]] = a[:, n]
+    return e
+
+
+@pytest.mark.parametrize("name", ["gb48", "ghp882"])
+def test_osd0_decoder_standalone_call(name):
+    """`OSD0_Decoder(n)(llr, pcm, s, bs)` as the reference's scripts call it (bp_osd.py:47-77, :147-157): the tiled full-rank basis as a
+    batched tensor, syndromes `[rank, bs]` — against a NumPy statement of the algorithm, sample by sample, and `pcm e_hat = s`."""
+    c = code(name)
+    basis = np.asarray(c.hx)[np.asarray(c.pivot_hx)].astype(np.uint8)
+    rank, n = basis.shape
+    B = 37
+    rng = np.random.RandomState(3)
+    llr = rng.uniform(-3.0, 6.0, size=(B, n)).astype(np.float32)
+    llr[:, ::7] = 1.5  # ties: the stable order decides
+    err = (rng.uniform(size=(B, n)) < 0.06).astype(np.uint8)
+    s = (err.astype(np.int64) @ basis.T.astype(np.int64) % 2).astype(np.int64).T  # [rank, bs]
+    osd = F.OSD0_Decoder(n)
+    pcm = torch.from_numpy(np.tile(basis[None], (B, 1, 1)).astype(np.int32)).cuda()
+    e_hat = osd(torch.from_numpy(llr).cuda(), pcm, torch.from_numpy(s).cuda(), B)
+    assert e_hat.dtype == torch.bool and tuple(e_hat.shape) == (B, n)
+    e = e_hat.cpu().numpy().astype(np.uint8)
+    assert np.array_equal(e.astype(np.int64) @ basis.T.astype(np.int64) % 2, s.T)
+    for b in range(B):
+        assert np.array_equal(e[b], _numpy_osd0(llr[b], basis, s[:, b].astype(np.uint8))), b
+    e2 = osd.call(llr, basis, s)  # a plain [rank, n] matrix, host inputs, the cached graph
+    assert torch.equal(e2, e_hat)
+    with pytest.raises(NotImplementedError):
+        bad = pcm.clone()
+        bad[1, 0, :] ^= 1
+        osd(torch.from_numpy(llr).cuda(), bad, torch.from_numpy(s).cuda(), B)
+
+
+def test_cal_logit_and_the_rest_of_the_decoder_surface():
+    """`QLDPCBPDecoder.cal_logit(llrx, llry, llrz)` (decoding_q.py:455-471) on the marginals a stage-one call returned = the soft
+    syndromes that call returned, bit for bit; `build` / `call` / `show_weights` and the read-only properties of `LDPCBPDecoder`
+    (decoding.py:420-494) exist with the reference's meaning."""
+    c = code("ghp882")
+    B = 11
+    og, ex, ez, sx, sz = _syndromes("ghp882", 0.09, B)
+    dec = F.QLDPCBPDecoder(code=c, num_iter=9, normalization_factor=0.8, cn_type="boxplus-phi", stage_one=True)
+    dec.build(None)
+    llr = torch.full((B, 3, c.N), llr_const(0.05), dtype=torch.float32, device="cuda")
+    llrx, llry, llrz, _, _, x_logit, z_logit = dec.call((llr, torch.from_numpy(sx.T.copy()).cuda(), torch.from_numpy(sz.T.copy()).cuda()))
+    xl, zl = dec.cal_logit(llrx.t(), llry.t(), llrz.t())
+    assert torch.equal(xl, x_logit) and torch.equal(zl, z_logit) and tuple(xl.shape) == (c.hz.shape[0], B)
+    with pytest.raises(NotImplementedError):
+        dec.show_weights()
+    b2 = F.LDPCBPDecoder(np.asarray(c.hx), cn_type="minsum", num_iter=7, normalization_factor=0.9, is_syndrome=True, hard_out=True)
+    assert (b2.num_cns, b2.num_vns, b2.num_edges) == (441, 882, 2646) and b2.has_weights is False and b2.llr_max == 20.0
+    assert np.array_equal(b2.pcm, np.asarray(c.hx)) and b2.output_dtype == torch.float32 and b2.num_iter == 7
+    b2.num_iter = 3
+    assert b2.num_iter == 3
+    with pytest.raises(AssertionError):
+        b2.num_iter = -1
+    for attr in ("edge_weights", "ie_c", "ie_v"):
+        with pytest.raises(NotImplementedError):
+            getattr(b2, attr)
+    out = b2.call((torch.full((B, 882), -1.4, dtype=torch.float32, device="cuda"), torch.from_numpy(sx.T.copy()).cuda()))
+    _, hard = og.bp2_decode(sx, 3, "minsum", 0.9, llr_const=-1.4)  # the oracle's binary BP on the hx graph (side 0 of the CSS graph)
+    assert np.array_equal(out.cpu().numpy().astype(np.uint8), hard)
