@@ -119,6 +119,11 @@ class Feedback_GNN:
                              cn(syndrome_x, g.m_x, torch.uint8), cn(syndrome_z, g.m_z, torch.uint8))
         return out.permute(0, 2, 1).contiguous()
 
+    call = __call__
+
+    def build(self, input_shape=None):
+        """Keras builds the Dense layers on the first call (feedback_gnn.py:110-128); here the weights exist after construction."""
+
 
 def load_weights(system, model_path):
     """`load_weights(G, path)` of gnn.py:774-791: reads the reference's pickle (restricted
@@ -129,25 +134,78 @@ def load_weights(system, model_path):
 class Pauli:
     """i.i.d. Pauli channel (sionna/channel/pauli.py:98-108) and, with ``wt=True``, the fixed-weight channel of :80-97.
 
-    ``Pauli(graph)((batch_size, px, py, pz))`` is not how the reference is called; the sandwich
-    model only ever uses px = pz = 2p/3, py = p/3 (feedback_gnn.py:298), which is what the library
-    implements.  Call ``channel(batch_size, p)`` → (noise_x, noise_z) uint8 [bs,n].  The stream is
-    counter-based (Philox4x32-10 keyed by seed and global sample index) so any sharding of a batch over
+    Native call (what the models here use): ``Pauli(graph, seed=, wt=)(batch_size, p[, first_sample])`` → (noise_x, noise_z) uint8
+    [bs, n].  The stream is counter-based (Philox4x32-10 keyed by seed and global sample index) so any sharding of a batch over
     GPUs sees the same samples.
-    """
 
-    def __init__(self, graph, seed=0x5EED, wt=False):
+    The reference's call (pauli.py:72-117) is accepted too: ``Pauli(wt=False)([cx, cz, px, py, pz])`` or, with ``wt=True``,
+    ``([cx, cz, wt])`` — ``cx`` gives the shape ``[bs, n]`` — returning bool tensors ``(noise_x, noise_z)`` when ``cz`` is None and
+    ``(y_x, y_z, noise_x, noise_z)`` otherwise.  Only the depolarizing split every caller of the reference uses is implemented,
+    ``px = pz = 2p/3, py = p/3`` (feedback_gnn.py:298, bp_osd.py:107): other triples raise NotImplementedError.  Successive
+    reference-style calls draw successive samples of the stream."""
+
+    def __init__(self, graph=None, seed=0x5EED, wt=False, dtype=None, device=None, **kwargs):
+        if isinstance(graph, bool):  # Pauli(True) would be dtype in the reference; be lenient with a positional wt
+            graph, wt = None, graph
         self.graph = graph
         self.seed = int(seed)
         self.wt = bool(wt)
+        self._device = device
+        self._next = 0  # sample-stream position of the reference-style calls
 
-    def __call__(self, batch_size, p, first_sample=0, out=None):
+    def _noise(self, B, n, p, first_sample, out, device):
+        if self.graph is not None:
+            if self.wt:
+                return self.graph.pauli_noise_wt(self.seed, int(p), first_sample, int(B), out=out)
+            return self.graph.pauli_noise(self.seed, p, first_sample, int(B), out=out)
+        # graph-less: the byte kernels need only n and a device
+        from . import _lib
+        from .graph import _ptr, _stream, check
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        ex = torch.empty((B, n), dtype=torch.uint8, device=dev)
+        ez = torch.empty((B, n), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            if self.wt:
+                check(_lib.lib().fgnn_pauli_noise_wt(self.seed, int(p), int(first_sample), int(B), int(n), _ptr(ex), _ptr(ez), _stream(dev)))
+            else:
+                check(_lib.lib().fgnn_pauli_noise(self.seed, float(np.float32(p)), int(first_sample), int(B), int(n), _ptr(ex), _ptr(ez),
+                                                  _stream(dev)))
+        return ex, ez
+
+    def __call__(self, batch_size, p=None, first_sample=0, out=None):
         """``p`` = physical error rate, or with ``wt=True`` the exact number of erroneous qubits per sample
         (pauli.py:80-97: positions uniform without replacement, X/Y/Z with probability 1/3 each).  ``out=(noise_x, noise_z)``
-        writes into given [batch_size, n] buffers."""
+        writes into given [batch_size, n] buffers.  A list / tuple as first argument is the reference's ``inputs``."""
+        if isinstance(batch_size, (list, tuple)):
+            return self._reference_call(batch_size)
+        if self.graph is None:
+            raise ValueError("Pauli(batch_size, p) needs the channel to be built on a graph: Pauli(graph, ...)")
+        return self._noise(batch_size, self.graph.n, p, first_sample, out, None)
+
+    def _reference_call(self, inputs):
         if self.wt:
-            return self.graph.pauli_noise_wt(self.seed, int(p), first_sample, int(batch_size), out=out)
-        return self.graph.pauli_noise(self.seed, p, first_sample, int(batch_size), out=out)
+            cx, cz, level = inputs
+            level = int(level)
+        else:
+            cx, cz, px, py, pz = inputs
+            px, py, pz = float(px), float(py), float(pz)
+            level = 3.0 * py
+            if abs(px - 2.0 * level / 3.0) > 1e-6 * max(level, 1e-30) or abs(pz - px) > 1e-6 * max(level, 1e-30):
+                raise NotImplementedError("Pauli: only the depolarizing split px = pz = 2p/3, py = p/3 is implemented")
+        cx_t = torch.as_tensor(cx)
+        if cx_t.dim() != 2:
+            raise ValueError("cx must have shape [batch_size, n]")
+        B, n = int(cx_t.shape[0]), int(cx_t.shape[1])
+        dev = self.graph.device if self.graph is not None else (cx_t.device if cx_t.is_cuda else self._device)
+        ex, ez = self._noise(B, n, level, self._next, None, dev)
+        self._next += B
+        noise_x, noise_z = ex.bool(), ez.bool()
+        if cx is not None and cz is not None:
+            return (torch.as_tensor(cx, device=ex.device).bool() ^ noise_x, torch.as_tensor(cz, device=ex.device).bool() ^ noise_z,
+                    noise_x, noise_z)
+        return noise_x, noise_z
+
+    call = __call__
 
 
 class Sandwich_BP_GNN_Evaluation_Model:

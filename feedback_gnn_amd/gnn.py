@@ -132,3 +132,8 @@ class GNN_BP4:
         out = g.gnn_bp4_decode(self._weights, prep(syndrome_x, g.m_x), prep(syndrome_z, g.m_z), self._num_iter)
         llr_hat = [(out["x_logit_all"][i].t(), out["z_logit_all"][i].t()) for i in range(self._num_iter)]
         return llr_hat, out["x_hat"].t().to(torch.int64), out["z_hat"].t().to(torch.float64)
+
+    call = __call__
+
+    def build(self, input_shape=None):
+        """Keras builds lazily (gnn.py:296-312); here the weights exist after construction."""

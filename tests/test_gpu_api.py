@@ -630,3 +630,27 @@ def test_cal_logit_and_the_rest_of_the_decoder_surface():
     out = b2.call((torch.full((B, 882), -1.4, dtype=torch.float32, device="cuda"), torch.from_numpy(sx.T.copy()).cuda()))
     _, hard = og.bp2_decode(sx, 3, "minsum", 0.9, llr_const=-1.4)  # the oracle's binary BP on the hx graph (side 0 of the CSS graph)
     assert np.array_equal(out.cpu().numpy().astype(np.uint8), hard)
+
+
+def test_pauli_channel_in_the_references_calling_convention():
+    """`Pauli(wt=False)([cx, cz, px, py, pz])` (pauli.py:72-117, as feedback_gnn.py:298-300 and bp_osd.py:107-109 call it): the
+    depolarizing split on a `[bs, n]` shape taken from `cx`, no graph needed — the same Philox samples as the native call and the
+    oracle; `cz` given -> (y_x, y_z, noise_x, noise_z); `wt=True` -> exactly `wt` errors per row; other (px, py, pz) are refused."""
+    c = code("ghp882")
+    B, p = 50, 0.09
+    og = oracle_library_forms("ghp882")
+    ch = F.Pauli(wt=False)
+    nx, nz = ch([torch.zeros((B, c.N)), None, 2 * p / 3, p / 3, 2 * p / 3])
+    ex, ez = og.pauli_noise(SEED, p, 0, B)
+    assert nx.dtype == torch.bool and np.array_equal(nx.cpu().numpy(), ex.astype(bool)) and np.array_equal(nz.cpu().numpy(), ez.astype(bool))
+    cx = torch.from_numpy((np.arange(B * c.N).reshape(B, c.N) % 3 == 0)).cuda()
+    yx, yz, nx2, nz2 = ch.call([cx, torch.zeros_like(cx), 2 * p / 3, p / 3, 2 * p / 3])  # the NEXT B samples of the stream
+    ex2, ez2 = og.pauli_noise(SEED, p, B, B)
+    assert np.array_equal(nx2.cpu().numpy(), ex2.astype(bool)) and torch.equal(yx, cx ^ nx2) and torch.equal(yz, nz2)
+    from helpers import gpu_graph
+    native = F.Pauli(gpu_graph("ghp882"))(B, p, 0)
+    assert torch.equal(native[0].bool(), nx) and torch.equal(native[1].bool(), nz)
+    wx, wz = F.Pauli(wt=True)([torch.zeros((B, c.N)), None, 7])
+    assert ((wx | wz).sum(1) == 7).all()
+    with pytest.raises(NotImplementedError):
+        ch([torch.zeros((B, c.N)), None, 0.05, 0.0, 0.0])  # a pure bit-flip channel is not the path's channel
