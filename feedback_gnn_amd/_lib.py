@@ -82,6 +82,7 @@ _SIGNATURES = {
     "fgnn_feedback_gnn": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_void_p]),
     "fgnn_pauli_noise": (C.c_int, [C.c_uint64, C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fgnn_pauli_noise_wt": (C.c_int, [C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fgnn_pauli_noise_dev": (C.c_int, [C.c_uint64, C.c_float, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fgnn_syndrome": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fgnn_flag_update": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p]),
     "fgnn_merge": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

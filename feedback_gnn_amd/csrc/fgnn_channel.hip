@@ -13,11 +13,14 @@
 namespace {
 
 // Pauli.call, sionna/channel/pauli.py:98-108.  One thread = 4 qubits of one sample (one Philox block).
-__global__ void __launch_bounds__(256) pauli_kernel(uint64_t seed, float p, uint64_t first, int B, int n, int nblk,
-                                                    uint8_t* __restrict__ ex, uint8_t* __restrict__ ez)
+// `base` (optional, device): the stream position the launch starts from is *base + first — a hipGraph that replays a Monte-Carlo loop
+// keeps its position in device memory and advances it itself (fgnn_pauli_noise_dev), so every replay draws fresh samples.
+__global__ void __launch_bounds__(256) pauli_kernel(uint64_t seed, float p, uint64_t first, const unsigned long long* __restrict__ base,
+                                                    int B, int n, int nblk, uint8_t* __restrict__ ex, uint8_t* __restrict__ ez)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)B * nblk) return;
+    if (base) first += (uint64_t)*base;
     const int b = (int)(t / nblk), blk = (int)(t - (long long)b * nblk);
     const fg_pauli_thr thr = fg_pauli_thresholds(p);
     float u[4];
@@ -338,7 +341,21 @@ extern "C" int fgnn_pauli_noise(uint64_t seed, float p, uint64_t first_sample, i
     const int nblk = (n + 3) / 4;
     const long long total = (long long)B * nblk;
     hipLaunchKernelGGL(pauli_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), seed,
-                       p, first_sample, B, n, nblk, noise_x, noise_z);
+                       p, first_sample, static_cast<const unsigned long long*>(nullptr), B, n, nblk, noise_x, noise_z);
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_pauli_noise_dev(uint64_t seed, float p, const uint64_t* first_sample_dev, uint64_t offset, int B, int n,
+                                    uint8_t* noise_x, uint8_t* noise_z, void* stream)
+{
+    if (B < 0 || n <= 0 || !(p >= 0.0f && p <= 1.0f)) return fgnn_fail(FGNN_ERR_ARG, "bad noise arguments");
+    if (B == 0) return FGNN_OK;
+    if (!noise_x || !noise_z || !first_sample_dev) return fgnn_fail(FGNN_ERR_ARG, "bad noise arguments");
+    const int nblk = (n + 3) / 4;
+    const long long total = (long long)B * nblk;
+    hipLaunchKernelGGL(pauli_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), seed,
+                       p, offset, reinterpret_cast<const unsigned long long*>(first_sample_dev), B, n, nblk, noise_x, noise_z);
     FGNN_HIP_CHECK(hipGetLastError());
     return FGNN_OK;
 }

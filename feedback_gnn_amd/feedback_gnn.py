@@ -334,6 +334,67 @@ class Sandwich_BP_GNN_Evaluation_Model:
         _, _, flags = self.graph.residual(o["noise_x"], o["noise_z"], o["x_hat"], o["z_hat"], want_arrays=False)
         return self.graph.count_flags(flags, counts)
 
+    def mc_graph(self, batch_size, p, steps, counts):
+        """``steps`` consecutive Monte-Carlo batches (noise -> syndromes -> sandwich -> residual -> counters, what ``steps`` calls of
+        `mc_step` enqueue) captured ONCE into a hipGraph; returns ``replay()``, a callable that runs them again on the NEXT
+        ``steps * world_size * batch_size`` samples of the stream with one graph launch and no other host work — the reference's
+        ``while`` loop of misc.py:636-738 with the host out of it.  The stream position lives in an 8-byte device counter that every
+        captured noise launch reads (fgnn_pauli_noise_dev) and the graph's last node advances; the host's own position is advanced
+        by `replay()`, so `mc_step` / `decode` calls in between continue where the graph left off.  ``counts`` (device int64[3]) is
+        the persistent accumulator the captured counting kernels add to.  For batches so small that a step is launch-bound
+        (BASELINE configs[0]: 256 codewords, five launches of 5-110 us); needs ``compact=False`` and ``streams=1``."""
+        if self.compact or self.streams > 1 or self.channel.wt:
+            raise ValueError("mc_graph captures the fixed i.i.d. dataflow: compact=False, streams=1, wt=False")
+        B, steps, g = int(batch_size), int(steps), self.graph
+        if steps < 1 or B < 1:
+            raise ValueError("steps and batch_size must be >= 1")
+        if counts.device != g.device or counts.dtype != torch.int64 or tuple(counts.shape) != (3,):
+            raise ValueError(f"counts must be int64[3] on {g.device}")
+        ctr = torch.tensor([self._next_sample], dtype=torch.int64, device=g.device)
+        span = self.world_size * B
+        L = self.num_layers
+        iters = [d.num_iter for d in self.decoders[:L]]
+        weights = [f.device_weights for f in self.feedbacks[:L - 1]]
+        factors = [d.normalization_factor for d in self.decoders[:L]]
+        cn_types = [d.cn_type for d in self.decoders[:L]]
+        if self._ws_batches[0] < B:
+            self._workspaces[0] = g.sandwich_workspace(B)
+            self._ws_batches[0] = B
+
+        def body(acc):
+            for j in range(steps):
+                ex, ez = g.pauli_noise(self.channel.seed, p, j * span + self.rank * B, B, first_dev=ctr)
+                sx, sz = g.syndrome(ex, ez)
+                o = g.sandwich_decode(sx, sz, iters, weights, self._llr_const(p), factors=factors, cn_types=cn_types, compact=False,
+                                      workspace=self._workspaces[0])
+                _, _, flags = g.residual(ex, ez, o["x_hat"], o["z_hat"], want_arrays=False)
+                g.count_flags(flags, acc)
+
+        # once eagerly (a capture must not be the first launch of a kernel: code objects load lazily) into a scratch accumulator,
+        # on a side stream as torch's capture protocol asks; the device counter is not advanced, so the capture starts at the same samples
+        side = torch.cuda.Stream(device=g.device)
+        side.wait_stream(torch.cuda.current_stream(g.device))
+        with torch.cuda.stream(side):
+            body(torch.zeros(3, dtype=torch.int64, device=g.device))
+        torch.cuda.current_stream(g.device).wait_stream(side)
+        torch.cuda.synchronize(g.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body(counts)
+            ctr.add_(steps * span)
+
+        expected = [self._next_sample]
+
+        def replay():
+            if self._next_sample != expected[0]:  # mc_step / decode / rewind moved the stream in between: tell the device counter
+                ctr.fill_(self._next_sample)
+            graph.replay()
+            self._next_sample += steps * span
+            expected[0] = self._next_sample
+
+        replay.graph, replay.steps, replay.counter = graph, steps, ctr
+        return replay
+
     def join(self):
         """``streams`` > 1: make the caller's current stream wait for every batch `mc_step` has issued on the side streams (a
         device-side wait, no host synchronisation).  Call it before the counters are read or zeroed."""

@@ -399,8 +399,10 @@ class TannerGraph:
         return grads
 
     # ---- channel / syndromes / flags / residual ---------------------------------------------------------
-    def pauli_noise(self, seed, p, first_sample, B, out=None):
-        """``out=(ex, ez)``: write into the given contiguous uint8 [B, n] tensors (row slices of a larger batch)."""
+    def pauli_noise(self, seed, p, first_sample, B, out=None, first_dev=None):
+        """``out=(ex, ez)``: write into the given contiguous uint8 [B, n] tensors (row slices of a larger batch).  ``first_dev`` (device
+        int64 / uint64 [1]): the stream position is read on the device, sample b = ``first_dev[0] + first_sample + b``
+        (fgnn_pauli_noise_dev: Monte-Carlo loops captured in a hipGraph)."""
         if out is None:
             ex = self._new((B, self.n), torch.uint8)
             ez = self._new((B, self.n), torch.uint8)
@@ -408,8 +410,14 @@ class TannerGraph:
             ex = self._chk_out(out[0], (B, self.n), torch.uint8, "noise_x")
             ez = self._chk_out(out[1], (B, self.n), torch.uint8, "noise_z")
         with torch.cuda.device(self.device):  # graph-less entry points run on the current device
-            check(_lib.lib().fgnn_pauli_noise(int(seed), float(np.float32(p)), int(first_sample), B, self.n, _ptr(ex), _ptr(ez),
-                                              _stream(self.device)))
+            if first_dev is None:
+                check(_lib.lib().fgnn_pauli_noise(int(seed), float(np.float32(p)), int(first_sample), B, self.n, _ptr(ex), _ptr(ez),
+                                                  _stream(self.device)))
+            else:
+                if first_dev.device != self.device or first_dev.dtype not in (torch.int64, torch.uint64) or first_dev.numel() != 1:
+                    raise ValueError(f"first_dev must be one int64 on {self.device}")
+                check(_lib.lib().fgnn_pauli_noise_dev(int(seed), float(np.float32(p)), _ptr(first_dev), int(first_sample), B, self.n,
+                                                      _ptr(ex), _ptr(ez), _stream(self.device)))
         return ex, ez
 
     def pauli_noise_wt(self, seed, wt, first_sample, B, out=None):

@@ -204,6 +204,11 @@ int fgnn_feedback_gnn(const fgnn_graph* g, const fgnn_weights* w, const float* l
  * (feedback_gnn.py:298): Philox4x32-10 stream keyed by (seed, first_sample + b). */
 int fgnn_pauli_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, uint8_t* noise_x, uint8_t* noise_z,
                      void* stream);
+/* The same with the stream position read on the DEVICE: sample b is keyed by (*first_sample_dev + offset + b).  For Monte-Carlo loops
+ * captured in a hipGraph (the reference's `while` loop of misc.py:636-738 with no host in it): the graph owns an 8-byte device counter,
+ * every noise launch of the captured loop reads it, and the graph's last node advances it, so each replay draws the next samples. */
+int fgnn_pauli_noise_dev(uint64_t seed, float p, const uint64_t* first_sample_dev, uint64_t offset, int B, int n, uint8_t* noise_x,
+                         uint8_t* noise_z, void* stream);
 /* Pauli.call with wt=True, pauli.py:80-97 (training-set harvesting, Generate_dataset.ipynb): exactly `wt` qubits per sample
  * carry an error, X / Y / Z with probability 1/3 each; positions by a Philox-driven partial Fisher-Yates shuffle. */
 int fgnn_pauli_noise_wt(uint64_t seed, int wt, uint64_t first_sample, int B, int n, uint8_t* noise_x, uint8_t* noise_z, void* stream);

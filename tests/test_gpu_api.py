@@ -654,3 +654,33 @@ def test_pauli_channel_in_the_references_calling_convention():
     assert ((wx | wz).sum(1) == 7).all()
     with pytest.raises(NotImplementedError):
         ch([torch.zeros((B, c.N)), None, 0.05, 0.0, 0.0])  # a pure bit-flip channel is not the path's channel
+
+
+@pytest.mark.parametrize("rank,world", [(0, 1), (1, 3)])
+def test_mc_graph_replays_equal_the_same_number_of_mc_steps(rank, world):
+    """`mc_graph`: K Monte-Carlo batches captured into one hipGraph whose noise launches read the stream position from a device counter
+    the graph advances itself — R replays add exactly what R * K `mc_step` calls add (same Philox samples, also on a rank of a
+    sharded stream), the host's stream position follows, and eager steps in between re-synchronise the device counter."""
+    c = code("ghp882")
+    B, p, K, R = 256, 0.11, 3, 4
+    eager, graphed = (_model(c, [32, 8], seed=9, rank=rank, world_size=world) for _ in range(2))
+    ce = torch.zeros(3, dtype=torch.int64, device="cuda")
+    cg = torch.zeros(3, dtype=torch.int64, device="cuda")
+    replay = graphed.mc_graph(B, p, K, cg)
+    assert cg.tolist() == [0, 0, 0] and graphed._next_sample == 0  # capturing runs nothing
+    for _ in range(R):
+        replay()
+    for _ in range(R * K):
+        eager.mc_step(B, p, ce)
+    torch.cuda.synchronize()
+    assert cg.tolist() == ce.tolist() and ce[2].item() == R * K * B and ce[1].item() > 0
+    assert graphed._next_sample == eager._next_sample == R * K * world * B
+    graphed.mc_step(B, p, cg)  # an eager batch in between moves the host's position only ...
+    eager.mc_step(B, p, ce)
+    replay()                   # ... the next replay starts behind it
+    for _ in range(K):
+        eager.mc_step(B, p, ce)
+    torch.cuda.synchronize()
+    assert cg.tolist() == ce.tolist() and graphed._next_sample == eager._next_sample
+    with pytest.raises(ValueError):
+        _model(c, [32, 8], compact=True).mc_graph(B, p, K, cg)
