@@ -684,3 +684,10 @@ def test_mc_graph_replays_equal_the_same_number_of_mc_steps(rank, world):
     assert cg.tolist() == ce.tolist() and graphed._next_sample == eager._next_sample
     with pytest.raises(ValueError):
         _model(c, [32, 8], compact=True).mc_graph(B, p, K, cg)
+    # the entry point the captured loop stands on: the stream position read on the device (fgnn_pauli_noise_dev) against the oracle
+    from helpers import gpu_graph
+    g = gpu_graph("ghp882")
+    pos = torch.tensor([(1 << 33) + 100], dtype=torch.int64, device="cuda")
+    dx, dz = g.pauli_noise(SEED, p, 7, 33, first_dev=pos)
+    ox, oz = oracle_library_forms("ghp882").pauli_noise(SEED, p, (1 << 33) + 107, 33)
+    assert np.array_equal(dx.cpu().numpy(), ox) and np.array_equal(dz.cpu().numpy(), oz)
