@@ -759,7 +759,8 @@ def main():
         with tempfile.TemporaryDirectory() as td:
             path = os.path.join(td, "cpu_legs.pkl")
             try:
-                rc = subprocess.call([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--cpu-legs-to", path, "--no-build"], cwd=ROOT)
+                rc = subprocess.call([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--cpu-legs-to", path, "--no-build"], cwd=ROOT,
+                                     stdout=sys.stderr)  # this process' stdout carries the ONE JSON line and nothing else
                 if rc != 0:
                     raise RuntimeError(f"exit code {rc}")
                 with open(path, "rb") as f:
