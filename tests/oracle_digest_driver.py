@@ -1,5 +1,5 @@
 """Digest of what the CPU oracle computes — run by tests/test_oracle_compilers.py once per host compiler (FGNN_ORACLE_LIB_PATH selects the
-build): sha256 over (a) the exhaustive-probe checksums of every shared-math / RNG routine on three 2^24-input slices of each of its
+build): sha256 over (a) the exhaustive-probe checksums of every shared-math / RNG routine on three 2^22-input slices of each of its
 domain ranges and (b) the complete outputs of every decode path on seeded inputs.  Prints one JSON object {name: hexdigest}."""
 import hashlib
 import json
@@ -30,7 +30,7 @@ out = {}
 for name, ranges in DOMAINS.items():
     parts = []
     for lo, hi in ranges:
-        span = min(1 << 24, hi - lo + 1)
+        span = min(1 << 22, hi - lo + 1)
         mid = lo + (hi - lo) // 2
         for a in sorted({lo, min(mid, hi - span + 1), hi - span + 1}):
             parts.append(O.math_checksums(name, a, a + span - 1, 22))

@@ -15,7 +15,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang"
 
 
 def _digests(lib_path=None):
-    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
     if lib_path:
         env["FGNN_ORACLE_LIB_PATH"] = lib_path
     else:
@@ -35,7 +35,10 @@ def test_gcc_and_clang_builds_of_the_oracle_compute_the_same_bits():
     res = subprocess.run([CLANG, "-O2", "-ffp-contract=off", "-mfma", "-fopenmp", "-fPIC", "-Wno-unused-function", "-shared",
                           os.path.join(ROOT, "oracle", "fgnn_oracle.c"), "-o", lib, "-lm"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert res.returncode == 0, res.stdout
-    gcc, clang = _digests(), _digests(lib)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as pool:  # the two digests side by side (each is mostly single-threaded: slices with denormal inputs are slow on x86)
+        fg, fc = pool.submit(_digests), pool.submit(_digests, lib)
+        gcc, clang = fg.result(), fc.result()
     assert len(gcc) >= 40 and sorted(gcc) == sorted(clang)
     diff = [k for k in gcc if gcc[k] != clang[k]]
     assert not diff, diff
