@@ -58,6 +58,7 @@ struct BpArgs {
     int hwt;                  // 1: v_exp_f32 / v_log_f32 instead of fgnn_math.h (FGNN_OPT_HW_TRANSCENDENTALS; phi rule, fixed dataflow)
     uint8_t* flagged;         // optional [B]: 1 iff the decision's syndrome differs from the measured one (feedback_gnn.py:324-328)
     int flag_off;             // float offset of n decision bytes + one word in LDS (only when flagged != null)
+    float* gmem;              // GMEM variant: workspace of (blocks * cpb) rows of lds_per_cw floats
     float* trace_x;           // TRACE variant: [num_iter+1, B, rows0] soft syndromes after 0, 1, ..., num_iter iterations (:743-746)
     float* trace_z;           //                [num_iter+1, B, rows1]
     int trace_off;            // float offset of the 2n binary LLRs the per-iteration soft syndromes are formed from
@@ -448,11 +449,15 @@ __device__ __forceinline__ float softplus_saturated(float t)
 // marginals are recorded after EVERY iteration (and before the first) by the kernel itself, from 2n binary LLRs in their own LDS
 // area — one launch instead of num_iter + 1 chained one-iteration launches with the messages going through HBM in between.  Same
 // float operations in the same order as the epilogue below, so the trace equals that chain's bit for bit.
-template <int CN_TYPE, int DVX, int DVZ, int DC, bool OPT, bool HWT = false, int NQ = 0, bool TRACE = false>
+// GMEM: the per-codeword state (messages, channel LLRs, epilogue scratch) lives in a global-memory workspace row instead of LDS — the
+// fallback for codes whose E + 3n floats exceed the CU's LDS (runtime degrees, fixed dataflow only).  Same float operations in the same
+// order; within a workgroup __syncthreads() orders the global stores of one phase before the loads of the next.
+template <int CN_TYPE, int DVX, int DVZ, int DC, bool OPT, bool HWT = false, int NQ = 0, bool TRACE = false, bool GMEM = false>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NQ > 0 ? FGNN_BP4_WAVES - 1 : FGNN_BP4_WAVES)))
 bp4_kernel(GraphDev g, BpArgs a)
 {
     static_assert(!(HWT && OPT), "the hardware-transcendental variant is the fixed dataflow only: the exact shortcuts are proofs about fgnn_math.h");
+    static_assert(!GMEM || (DVX == 0 && !OPT && !HWT && NQ == 0 && !TRACE), "the global-memory variant is the plain runtime-degree kernel");
     using MX = Mx<HWT>;
     FG_LOG_TAB_SETUP();
     constexpr bool REGULAR = DVX > 0;
@@ -467,7 +472,9 @@ bp4_kernel(GraphDev g, BpArgs a)
     const int slot_b = blockIdx.x * a.cpb + cwl;
     const bool active = slot_b < a.B;  // padding codewords of the last block only keep the barriers company
     const int b = (active && a.index) ? a.index[slot_b] : slot_b;
-    float* msg = lds + (size_t)cwl * a.lds_per_cw;
+    float* msg;
+    if constexpr (GMEM) msg = a.gmem + (size_t)slot_b * a.lds_per_cw;
+    else msg = lds + (size_t)cwl * a.lds_per_cw;
     float* Lch = msg + a.lch_off;  // [3n], only when llr_ch != null
     const int n = g.n;
 
@@ -986,6 +993,7 @@ static int bp4_decode_core(const fgnn_graph* g, int cn_type, int num_iter, float
     a.trace_off = 0;
     a.tape_x = tape_x;
     a.tape_z = tape_z;
+    a.gmem = nullptr;
     a.shared_lse = g->bp4_shared_lse ? 1 : 0;
     // the trace variant is the fixed dataflow on the shared float32 routines, channel LLRs in LDS
     a.hwt = (g->hw_transcendentals && cn_type == FGNN_CN_BOXPLUS_PHI && !trace) ? 1 : 0;
@@ -1037,8 +1045,49 @@ static int bp4_decode_core(const fgnn_graph* g, int cn_type, int num_iter, float
         static const long pad = getenv("FGNN_BP4_LDS_PAD") ? atol(getenv("FGNN_BP4_LDS_PAD")) : 0;
         if (pad > 0 && lds_bytes + (size_t)pad <= FGNN_LDS_BUDGET) lds_bytes += (size_t)pad;
     }
-    if (lds_bytes > FGNN_LDS_BUDGET) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident kernel");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (lds_bytes > FGNN_LDS_BUDGET) {
+        // The codeword's state does not fit a CU's LDS (about E + 3n > 40 000 floats): run the same runtime-degree kernel with that
+        // state in a global-memory workspace row per workgroup slot (bp4_kernel<..., GMEM>).  Fixed dataflow, float32 routines of
+        // fgnn_math.h, no trace: the reference's tensors are in device memory too, so this is its dataflow with the iterations fused
+        // into one launch.  The workspace is stream-ordered (allocated and freed on the caller's stream, no synchronisation).
+        if (trace) return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident trace kernel");
+        if (L.cpb != 1) return fgnn_fail(FGNN_ERR_STATE, "the global-memory BP4 variant needs one codeword per workgroup");
+        a.shortcut = a.early_exit = a.hwt = a.lreg = 0;
+        int per = a.lch_off + (llr_ch ? 3 * g->d.n : 0);
+        a.sig_off = per;
+        if (flagged) {  // n decision bytes + one word, behind the 2n floats the soft-syndrome epilogue reuses when they fit, else behind everything
+            const size_t need = (size_t)((g->d.n + 3) & ~3) + sizeof(unsigned);
+            if ((size_t)a.lch_off * sizeof(float) >= (size_t)2 * g->d.n * sizeof(float) + need) a.flag_off = 2 * g->d.n;
+            else {
+                a.flag_off = per;
+                per += (int)((need + sizeof(float) - 1) / sizeof(float));
+            }
+        }
+        per = (per + 3) & ~3;
+        a.lds_per_cw = per;
+        const size_t ws_bytes = (size_t)L.blocks * (size_t)per * sizeof(float);
+        void* ws = nullptr;
+        FGNN_HIP_CHECK(hipMallocAsync(&ws, ws_bytes, st));
+        a.gmem = static_cast<float*>(ws);
+        fgnn_prof_scope prof(g, st);
+        switch (cn_type) {
+        case FGNN_CN_BOXPLUS_PHI:
+            hipLaunchKernelGGL((bp4_kernel<FGNN_CN_BOXPLUS_PHI, 0, 0, 0, false, false, 0, false, true>), dim3(L.blocks), dim3(L.threads), 0, st, g->d, a);
+            break;
+        case FGNN_CN_MINSUM:
+            hipLaunchKernelGGL((bp4_kernel<FGNN_CN_MINSUM, 0, 0, 0, false, false, 0, false, true>), dim3(L.blocks), dim3(L.threads), 0, st, g->d, a);
+            break;
+        default:
+            hipLaunchKernelGGL((bp4_kernel<FGNN_CN_BOXPLUS, 0, 0, 0, false, false, 0, false, true>), dim3(L.blocks), dim3(L.threads), 0, st, g->d, a);
+            break;
+        }
+        const hipError_t launched = hipGetLastError();
+        (void)hipFreeAsync(ws, st);
+        FGNN_HIP_CHECK(launched);
+        prof.done(num_iter, B);
+        return FGNN_OK;
+    }
     fgnn_prof_scope prof(g, st);
     int rc;
     switch (cn_type) {

@@ -27,7 +27,7 @@ def _built_libraries():
 # failure can never again stop the run before the parity suite has been seen (round-4 GPUTEST: a bench-contract assertion sorted before
 # every test_g*.py and `-x` skipped 294 parity tests).
 _PARITY_FIRST = ("test_abi", "test_math", "test_gpu_math_bits", "test_golden_outputs", "test_gpu_parity", "test_gpu_pins",
-                 "test_gpu_literal_forms", "test_gpu_gnn_order", "test_gpu_bp4_shared_lse", "test_gpu_api")
+                 "test_gpu_literal_forms", "test_gpu_gnn_order", "test_gpu_bp4_shared_lse", "test_gpu_big_codes", "test_gpu_api")
 _HARNESS_LAST = ("test_gpu_backward", "test_gpu_dist", "test_gpu_rccl", "test_distributed_cpu", "test_launch", "test_bench_contract")
 
 

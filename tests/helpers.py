@@ -33,6 +33,21 @@ def _overcomplete(key):
     return cq.css_code(hx=unpack(g, key, "hx").astype(int), hz=unpack(g, key, "hz").astype(int), name=None, name_prefix="GB")
 
 
+def _hp_big():
+    """A hypergraph product too large for a CU's LDS: [[6480, 1296]] from a seeded (3,6)-like 36 x 72 matrix — 45 576 edges, so the BP4
+    state of one codeword (E + 3n = 65 016 floats = 254 KB) takes the library's global-memory variant of the runtime-degree kernel."""
+    rng = np.random.RandomState(7)
+    m, n, dv = 36, 72, 3
+    per = dv * n // m // dv
+    h = np.zeros((m, n), dtype=int)
+    for _ in range(dv):
+        perm = rng.permutation(n)
+        for r in range(m):
+            h[r, perm[r * per:(r + 1) * per]] = 1
+    return cq.hypergraph_product(h, h, "HP_n6480_lds_overflow")
+
+
+CODE_MAKERS["hp_big"] = _hp_big
 CODE_MAKERS["gb46_oc"] = lambda: _overcomplete("gb46_oc")
 CODE_MAKERS["gb48_oc"] = lambda: _overcomplete("gb48_oc")
 

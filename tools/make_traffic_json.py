@@ -81,7 +81,8 @@ for spec in sys.argv[2:]:
     if kind == "sandwich":
         # the FIRST decoder's launch (constant channel LLR: template argument NQ = 0) — the later decoders of a sandwich carry
         # their per-qubit channel LLRs in registers (NQ = 4 / 5) and are a different instantiation
-        bp = pick(rows, "bp4_kernel", lambda nm: re.search(r",\s*0,\s*false>$", nm) is not None)
+        # (template tail: ..., NQ, TRACE, GMEM> — GMEM appeared in round 5; the round-4 summaries end in NQ, TRACE>)
+        bp = pick(rows, "bp4_kernel", lambda nm: re.search(r",\s*0,\s*false(,\s*false)?>$", nm) is not None)
         if bp:
             (name, wg), v = bp
             out[f"bp4_{code}_it{iters}_B{B}{suffix}"] = entry("bp4", name, v)
