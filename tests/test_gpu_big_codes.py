@@ -20,12 +20,14 @@ def _inputs(B, p, first=3):
     return og, ex, ez, sx, sz
 
 
-@pytest.mark.parametrize("cn_type,factor,per_qubit", [("boxplus-phi", 1.0, False), ("boxplus-phi", 0.8, True), ("minsum", 0.8, True),
-                                                       ("boxplus", 0.625, False)])
-def test_bp4_on_a_code_beyond_the_lds_budget(cn_type, factor, per_qubit):
+@pytest.mark.parametrize("cn_type,factor,per_qubit,B", [("boxplus-phi", 1.0, False, 5), ("boxplus-phi", 0.8, True, 5), ("minsum", 0.8, True, 5),
+                                                         ("boxplus", 0.625, False, 5), ("boxplus-phi", 1.0, True, 261)])
+def test_bp4_on_a_code_beyond_the_lds_budget(cn_type, factor, per_qubit, B):
+    """B = 5 launches a thread per node (1 024 threads per codeword: the small-launch geometry), B = 261 the 256-thread geometry of
+    chip-filling launches."""
     c = code("hp_big")
     assert c.N == 6480 and int(c.hx.sum() + c.hz.sum()) > 40896  # messages alone overflow 160 KB
-    B, IT = 5, 6
+    IT = 6
     og, ex, ez, sx, sz = _inputs(B, 0.03)
     gg = gpu_graph("hp_big")
     kw = dict(llr_const=llr_const(0.05))
