@@ -593,6 +593,10 @@ def sandwich_roofline(code_name, dims, launches, launches_per_step, B, iters, fa
             "effective_bandwidth_frac": eff_gbs / HBM_PEAK_GBS if eff_gbs else None,
             "effective_bandwidth_GBs": eff_gbs, "hbm_peak_GBs": HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": alg_bytes,
+            # the same figures in the shape of the task contract's roofline object (bound "hbm"): SURVEY 8(d) bytes per launch / the launch's
+            # HIP-event duration against the 8 TB/s peak — an EFFECTIVE bandwidth (frac > 1: the messages never travel); traffic = measured bytes
+            "contract_hbm": {"bound": "hbm", "achieved": eff_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": eff_gbs / HBM_PEAK_GBS if eff_gbs else None, "traffic": traffic, "effective": True},
             "gnn": feedback_gnn_roofline(code_name, dims, launches, B, factored, stream) if len(iters) > 1 else None,
             "note": "bound = VALU issue: all messages stay in LDS for the 64 iterations, the kernel issues the exp/log "
                     "instruction streams of fgnn_math.h (DESIGN.md §4.1).  frac = SQ_INSTS_VALU per launch (offline PMC pass, "
@@ -1042,6 +1046,7 @@ def main():
             r = out["roofline"]
             for k in ("frac", "achieved", "frac_of_hw_transcendental_rate", "effective_bandwidth_frac", "effective_bandwidth_GBs", "hbm_frac"):
                 r[k] = None
+            r["contract_hbm"]["achieved"] = r["contract_hbm"]["frac"] = None
             r["traffic_source"] = (f"--streams {args.streams}: per-launch HIP-event durations overlap between streams; the roofline fractions are "
                                    "quoted for one-stream runs only")
             if r.get("gnn"):
