@@ -48,6 +48,9 @@ def test_bench_prints_one_contract_line():
     assert r["launches_timed"] == 2 and r["hbm_peak_GBs"] == 8000.0
     eff = r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9
     assert abs(r["effective_bandwidth_GBs"] - eff) < 1e-6 * eff and abs(r["effective_bandwidth_frac"] - eff / 8000.0) < 1e-9
+    ch = r["contract_hbm"]  # the same figure in the contract's own shape, labelled effective
+    assert ch["bound"] == "hbm" and ch["unit"] == "GB/s" and ch["peak"] == 8000.0 and ch["effective"] is True
+    assert ch["achieved"] == r["effective_bandwidth_GBs"] and abs(ch["frac"] - r["effective_bandwidth_frac"]) < 1e-12 and ch["traffic"] == r["traffic"]
     # the second kernel's roofline, timed in the same run by the same HIP-event recorder: at 2 048 codewords the library runs the feedback
     # GNN on its MFMA tiles (the streaming VALU kernel takes over from 4 096 on), priced in the reference's FLOPs against the f32 peak
     gn = r["gnn"]
