@@ -11,6 +11,7 @@
   c1  configs[0]  [[882,24]]  BP4-32 alone, 256 codewords, p = 0.05, AS THE REFERENCE CONSTRUCTS IT: cn_type='boxplus', normalization_factor
                   0.625 (decoding_q.py:18-22); `--cn-type boxplus-phi` is the QLDPC.ipynb cell 11 helper's variant.  A latency figure.
   c2  configs[1]  [[882,24]]  BP4-64 alone, 65 536 codewords (the first launch of c3)
+  qldpc_882 / qldpc_1270   plain BP4-64 as examples/QLDPC.ipynb cell 12 runs it (boxplus-phi, factor 0.8, p0 = 0.3, batch 10 000, p = 0.01)
   n882_3r / n882_5r / n1270_3r   the workloads of the reference's only published timings (one RTX 4090, TF-XLA):
                   (64, G, 16) x 3 or 5 feedback rounds, batch_size 5 000, p = 0.05 / 0.07 (n882.py:13,39,56-66, n1270.py:57-70); timed on one
                   stream (`value`) and with consecutive batches alternating between two HIP streams (`two_streams`) in the same run.
@@ -92,8 +93,13 @@ CONFIGS = {
                     baseline="none — the reference's published workload n882.py:13,45-66 (nG = 5; examples/n882.ipynb cell 3), 7.50 k cw/s on an RTX 4090"),
     "n1270_3r": dict(code="ghp1270", iters="64,16,16,16", batch=5000, p=0.07,
                      baseline="none — the reference's published workload examples/n1270.ipynb cell 2 (n1270.py:57-70 with nG = 3), 6.39 k cw/s on an RTX 4090"),
+    # plain BP4 as examples/QLDPC.ipynb cell 12 runs it (helper `define_code`: 64 iterations, boxplus-phi, factor 0.8, p0 = 0.3, batch 10 000)
+    "qldpc_882": dict(code="ghp882", iters="64", batch=10000, p=0.01, cn_type="boxplus-phi", factor=0.8, p0=0.3,
+                      baseline="none — the reference's published workload examples/QLDPC.ipynb cell 12, table GHP_n882_k24, row p = 0.01: 29.7 k cw/s on an RTX 4090"),
+    "qldpc_1270": dict(code="ghp1270", iters="64", batch=10000, p=0.01, cn_type="boxplus-phi", factor=0.8, p0=0.3,
+                       baseline="none — the reference's published workload examples/QLDPC.ipynb cell 12, table GHP_n1270_k28, row p = 0.01: 17.3 k cw/s on an RTX 4090"),
 }
-PUBLISHED_CONFIGS = ("n882_3r", "n882_5r", "n1270_3r")
+PUBLISHED_CONFIGS = ("n882_3r", "n882_5r", "n1270_3r", "qldpc_882", "qldpc_1270")
 CN_TYPES = ("boxplus", "boxplus-phi", "minsum")
 PROF_TAG_GNN, PROF_TAG_GNNBP4 = -1, -2  # fgnn_profile_read tags (include/fgnn.h)
 
@@ -191,6 +197,9 @@ def parse_args(argv=None):
     ap.add_argument("--factor", type=float, default=None,
                     help="normalization_factor of every decoder (decoding_q.py:22: class default 0.625; n882.py:58-59: 1.0); default: the "
                          "configuration's (c1: 0.625, every other: 1.0)")
+    ap.add_argument("--p0", type=float, default=None,
+                    help="the p0 the channel LLR log(3(1-p0)/p0) of the first decoder is formed from (feedback_gnn.py:265,311-312: 0.05; "
+                         "QLDPC.ipynb cell 12: 0.3); default: the configuration's")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams consecutive batches alternate between (Sandwich_BP_GNN_Evaluation_Model(streams=)); the published-workload "
                          "configurations time 1 and 2 in the same run")
@@ -218,6 +227,7 @@ def parse_args(argv=None):
     args.p = cfg.get("p", 0.01) if args.p is None else args.p
     args.cn_type = cfg.get("cn_type", "boxplus-phi") if args.cn_type is None else args.cn_type
     args.factor = cfg.get("factor", 1.0) if args.factor is None else args.factor
+    args.p0 = cfg.get("p0", 0.05) if args.p0 is None else args.p0
     if args.streams < 1:
         ap.error("--streams must be >= 1")
     return args
@@ -322,7 +332,7 @@ def cpu_legs(args, code, wname, iters, seed, factored):
     share = host_cpu_share()
     if "OMP_NUM_THREADS" not in os.environ:
         set_num_threads(share)
-    L0 = llr_const(0.05)
+    L0 = llr_const(args.p0)
     w = read_weight_list(wname)
     cpu_model = _cpu_model()
     shared = os.environ.get("FGNN_BENCH_BP4_LSE", "shared") != "literal"
@@ -633,7 +643,7 @@ def gnnbp4_forms_agreement(g, wdev, sx, sz, num_iter, workspace):
             "max_abs_dllr": float(d.max()), "samples_gt_1e_4": int((d > 1e-4).sum())}
 
 
-def sandwich_extras(g, model, code, decs, G, iters, B, p, seed, literal_value, cn_type="boxplus-phi", factor=1.0):
+def sandwich_extras(g, model, code, decs, G, iters, B, p, seed, literal_value, cn_type="boxplus-phi", factor=1.0, p0=0.05):
     """`extras` of a single-GPU c3 / c4 run: the variants that are NOT the headline — BP4 alone (configs[1]), the product default (exact
     shortcuts, compaction: identical outputs) and the opt-in hardware-transcendental BP4 with its measured distance from the exact kernel."""
     import numpy as np
@@ -658,14 +668,14 @@ def sandwich_extras(g, model, code, decs, G, iters, B, p, seed, literal_value, c
     cs = torch.zeros(3, dtype=torch.int64, device="cuda")
     t_s = timed(lambda: model.mc_step(B, p, cs))
     g.set_saturation_shortcut(False)
-    model_c = F.Sandwich_BP_GNN_Evaluation_Model(code, decs, [G] * (len(iters) - 1), num_layers=len(iters), p0=0.05, seed=seed, compact=True)
+    model_c = F.Sandwich_BP_GNN_Evaluation_Model(code, decs, [G] * (len(iters) - 1), num_layers=len(iters), p0=p0, seed=seed, compact=True)
     cc = torch.zeros(3, dtype=torch.int64, device="cuda")
     t_c = timed(lambda: model_c.mc_step(B, p, cc))
     g.set_saturation_shortcut(True)
     t_cs = timed(lambda: model_c.mc_step(B, p, cc))
     g.set_saturation_shortcut(False)
     # the headline's fixed dataflow with consecutive batches alternating between two HIP streams (own workspaces, shared atomic counters)
-    model_2s = F.Sandwich_BP_GNN_Evaluation_Model(code, decs, [G] * (len(iters) - 1), num_layers=len(iters), p0=0.05, seed=seed, streams=2)
+    model_2s = F.Sandwich_BP_GNN_Evaluation_Model(code, decs, [G] * (len(iters) - 1), num_layers=len(iters), p0=p0, seed=seed, streams=2)
     c2 = torch.zeros(3, dtype=torch.int64, device="cuda")
 
     def two_stream_steps():
@@ -881,7 +891,7 @@ def main():
                            activation="tanh", use_bias=True, graph=g)
         F.load_weights(G, wname)
         def make_model(streams):
-            return F.Sandwich_BP_GNN_Evaluation_Model(code, decs, [G] * (len(iters) - 1), num_layers=len(iters), p0=0.05, seed=SEED,
+            return F.Sandwich_BP_GNN_Evaluation_Model(code, decs, [G] * (len(iters) - 1), num_layers=len(iters), p0=args.p0, seed=SEED,
                                                       rank=rank, world_size=world, streams=streams)
 
         model = make_model(args.streams)
@@ -1013,17 +1023,18 @@ def main():
             ref_construction = ("the reference's constructor defaults, decoding_q.py:18-22" if (args.cn_type, args.factor) == ("boxplus", 0.625) else
                                 "as the reference's scripts construct it, n882.py:56-62" if (args.cn_type, args.factor) == ("boxplus-phi", 1.0) else
                                 "the QLDPC.ipynb cell 11 helper's construction" if (args.cn_type, args.factor) == ("boxplus-phi", 0.625) else
+                                "as QLDPC.ipynb cell 12 constructs it" if (args.cn_type, args.factor, args.p0) == ("boxplus-phi", 0.8, 0.3) else
                                 "construction given on the command line")
             out = dict({"metric": metric}, **common, **{
                 "config": {"workload": (f"{code.name} BP4-{iters[0]} alone (one QLDPCBPDecoder launch per step), " if len(iters) == 1 else
                                         f"{code.name} sandwich BP4-{'+'.join(map(str, iters))} with {len(iters) - 1} feedback-GNN "
                                         f"pass(es), trained weights {wname}, ") +
-                                       f"cn_type={args.cn_type}, normalization_factor={args.factor} ({ref_construction}), p0=0.05, "
+                                       f"cn_type={args.cn_type}, normalization_factor={args.factor} ({ref_construction}), p0={args.p0}, "
                                        f"depolarizing p={args.p}, "
                                        f"noise+syndrome+decode+residual+count on device (BASELINE.json "
                                        f"{cfg['baseline'] if is_cfg_shape else 'shape given on the command line'})",
                            "code": code.name, "batch_per_gpu": B, "global_batch": world * B, "bp_iters": iters, "p": args.p,
-                           "cn_type": args.cn_type, "normalization_factor": args.factor, "streams": args.streams,
+                           "cn_type": args.cn_type, "normalization_factor": args.factor, "p0": args.p0, "streams": args.streams,
                            "parallelism": f"batch-sharded x{world}, no data-path collective",
                            "threads_per_codeword": info["threads_per_codeword"], "seed": SEED,
                            "gnn_association": "factored" if factored else "literal",
@@ -1070,7 +1081,7 @@ def main():
         if is_c5:
             fa = gnnbp4_forms_agreement(g, wdev, sx, sz, iters[0], ws)
         else:
-            fa = g.forms_agreement(sx, sz, iters, [G.device_weights] * (len(iters) - 1), llr_const(0.05),
+            fa = g.forms_agreement(sx, sz, iters, [G.device_weights] * (len(iters) - 1), llr_const(args.p0),
                                    factors=[args.factor] * len(iters), cn_types=[args.cn_type] * len(iters))
         fa["p"] = args.p
         fa["what"] = ("the first timed batch of rank 0 decoded under the default forms and under the literal forms (both this library's "
@@ -1092,7 +1103,7 @@ def main():
                 d = g.gnn_bp4_decode(wdev, sx, sz, iters[0], return_logits=False)
                 d["noise_x"], d["noise_z"] = ex, ez
             else:
-                m2 = F.Sandwich_BP_GNN_Evaluation_Model(code, decs, [G] * (len(iters) - 1), num_layers=len(iters), p0=0.05, seed=SEED)
+                m2 = F.Sandwich_BP_GNN_Evaluation_Model(code, decs, [G] * (len(iters) - 1), num_layers=len(iters), p0=args.p0, seed=SEED)
                 d = m2.decode(S, args.p, first_sample=0)
             _, _, gfl = g.residual(d["noise_x"], d["noise_z"], d["x_hat"], d["z_hat"], want_arrays=False)
             same = bool(np.array_equal(fl, gfl.cpu().numpy()) and np.array_equal(o["x_hat"], d["x_hat"].cpu().numpy())
@@ -1105,7 +1116,7 @@ def main():
             out["speedup_vs_cpu_tf_like"] = value / out["cpu_baseline_tf_like"]["value"]
         if not args.no_extras and not is_c5:
             out["extras"] = sandwich_extras(g, model, code, decs, G, iters, B, args.p, SEED, (out["literal_forms"] or {}).get("value"),
-                                            args.cn_type, args.factor)
+                                            args.cn_type, args.factor, args.p0)
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()

@@ -106,6 +106,10 @@ def test_config_shapes_and_the_algorithmic_counts_of_the_other_two_configs():
     assert (a.code, a.iters, a.batch, a.p) == ("ghp882", "64,16,16,16,16,16", 5000, 0.05)
     a = bench.parse_args(["--config", "n1270_3r"])
     assert (a.code, a.iters, a.batch, a.p) == ("ghp1270", "64,16,16,16", 5000, 0.07)
+    a = bench.parse_args(["--config", "qldpc_882"])  # plain BP4 as QLDPC.ipynb cell 12 runs it (29.7 k cw/s published)
+    assert (a.code, a.iters, a.batch, a.p, a.cn_type, a.factor, a.p0) == ("ghp882", "64", 10000, 0.01, "boxplus-phi", 0.8, 0.3)
+    a = bench.parse_args(["--config", "qldpc_1270"])
+    assert (a.code, a.batch, a.p0) == ("ghp1270", 10000, 0.3) and bench.parse_args([]).p0 == 0.05
     a = bench.parse_args(["--config", "c2"])  # configs[1]: BP4-64 alone
     assert (a.code, a.iters, a.batch, a.p) == ("ghp882", "64", 65536, 0.01)
     a = bench.parse_args(["--config", "c4"])
