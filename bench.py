@@ -12,6 +12,8 @@
                   0.625 (decoding_q.py:18-22); `--cn-type boxplus-phi` is the QLDPC.ipynb cell 11 helper's variant.  A latency figure.
   c2  configs[1]  [[882,24]]  BP4-64 alone, 65 536 codewords (the first launch of c3)
   qldpc_882 / qldpc_1270   plain BP4-64 as examples/QLDPC.ipynb cell 12 runs it (boxplus-phi, factor 0.8, p0 = 0.3, batch 10 000, p = 0.01)
+  osd_bp4_minsum   BP4 min-sum, 120 iterations, factor 0.8, 50 000 samples at p = 0.09 (examples/OSD.ipynb cell 6, "bp Elapsed time")
+  n1270_5r / n1270_coarse   n1270.ipynb cells 4 and 9 (five rounds at p = 0.08; the coarse GNN at p = 0.02)
   n882_3r / n882_5r / n1270_3r   the workloads of the reference's only published timings (one RTX 4090, TF-XLA):
                   (64, G, 16) x 3 or 5 feedback rounds, batch_size 5 000, p = 0.05 / 0.07 (n882.py:13,39,56-66, n1270.py:57-70); timed on one
                   stream (`value`) and with consecutive batches alternating between two HIP streams (`two_streams`) in the same run.
@@ -93,13 +95,20 @@ CONFIGS = {
                     baseline="none — the reference's published workload n882.py:13,45-66 (nG = 5; examples/n882.ipynb cell 3), 7.50 k cw/s on an RTX 4090"),
     "n1270_3r": dict(code="ghp1270", iters="64,16,16,16", batch=5000, p=0.07,
                      baseline="none — the reference's published workload examples/n1270.ipynb cell 2 (n1270.py:57-70 with nG = 3), 6.39 k cw/s on an RTX 4090"),
+    "n1270_5r": dict(code="ghp1270", iters="64,16,16,16,16,16", batch=5000, p=0.08,
+                     baseline="none — the reference's published workload examples/n1270.ipynb cell 4 (nG = 5), 4.46 k cw/s on an RTX 4090"),
+    "n1270_coarse": dict(code="ghp1270", iters="64,16", batch=5000, p=0.02, weights="feedback_GNN_n1270_k28_wt_10_60_iter_16_16.npz",
+                         baseline="none — the reference's published workload examples/n1270.ipynb cell 9: (64, G_coarse, 16), 10.9 k cw/s on an RTX 4090"),
+    # BP4 min-sum as examples/OSD.ipynb cell 6 times it ("bp Elapsed time": noise + syndromes + 120 min-sum iterations on 50 000 samples)
+    "osd_bp4_minsum": dict(code="ghp882", iters="120", batch=50000, p=0.09, cn_type="minsum", factor=0.8, p0=0.09,
+                           baseline="none — the reference's published timing examples/OSD.ipynb cell 6, 50 000 / 3.96 s = 12.6 k cw/s on an RTX 4090"),
     # plain BP4 as examples/QLDPC.ipynb cell 12 runs it (helper `define_code`: 64 iterations, boxplus-phi, factor 0.8, p0 = 0.3, batch 10 000)
     "qldpc_882": dict(code="ghp882", iters="64", batch=10000, p=0.01, cn_type="boxplus-phi", factor=0.8, p0=0.3,
                       baseline="none — the reference's published workload examples/QLDPC.ipynb cell 12, table GHP_n882_k24, row p = 0.01: 29.7 k cw/s on an RTX 4090"),
     "qldpc_1270": dict(code="ghp1270", iters="64", batch=10000, p=0.01, cn_type="boxplus-phi", factor=0.8, p0=0.3,
                        baseline="none — the reference's published workload examples/QLDPC.ipynb cell 12, table GHP_n1270_k28, row p = 0.01: 17.3 k cw/s on an RTX 4090"),
 }
-PUBLISHED_CONFIGS = ("n882_3r", "n882_5r", "n1270_3r", "qldpc_882", "qldpc_1270")
+PUBLISHED_CONFIGS = ("n882_3r", "n882_5r", "n1270_3r", "n1270_5r", "n1270_coarse", "osd_bp4_minsum", "qldpc_882", "qldpc_1270")
 CN_TYPES = ("boxplus", "boxplus-phi", "minsum")
 PROF_TAG_GNN, PROF_TAG_GNNBP4 = -1, -2  # fgnn_profile_read tags (include/fgnn.h)
 
@@ -745,6 +754,7 @@ def main():
     is_c5 = args.config == "c5"
     iters = [int(x) for x in args.iters.split(",")]
     code, wname = make_code(args.code)
+    wname = CONFIGS[args.config].get("weights", wname)  # (n1270_coarse: the coarse GNN of n1270.ipynb cell 9)
     factored = os.environ.get("FGNN_BENCH_GNN_ORDER", "factored") != "literal"  # the library default; "literal" times the other order
     # both associations run on the streaming VALU kernel by default (the library's choice at these batch sizes);
     # FGNN_BENCH_GNN_KERNEL=mfma times the MFMA-tile kernel

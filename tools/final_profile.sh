@@ -18,7 +18,7 @@ tail -2 $O/pytest_gpu.log
 fi
 if has counts; then
 # counts first: the bench lines below then quote THIS library's PMC passes (library_is_the_profiled_binary: true)
-bash tools/refresh_traffic.sh $TAG c1 c1phi c3 c4 c5 n882 n1270 q882 q1270 > $O/refresh.log 2>&1
+bash tools/refresh_traffic.sh $TAG c1 c1phi c3 c4 c5 n882 n1270 q882 q1270 osdms > $O/refresh.log 2>&1
 cp $O/traffic.json profiles/traffic.json
 fi
 if has lines; then
@@ -33,6 +33,9 @@ python bench.py --no-build --config c2 --require-roofline > $O/bench_c2.json 2>>
 python bench.py --no-build --config n882_3r --steps 100 --warmup 5 --require-roofline > $O/bench_n882_3r.json 2>> $O/bench.err
 python bench.py --no-build --config n882_5r --steps 100 --warmup 5 --require-roofline > $O/bench_n882_5r.json 2>> $O/bench.err
 python bench.py --no-build --config n1270_3r --steps 100 --warmup 5 --require-roofline > $O/bench_n1270_3r.json 2>> $O/bench.err
+python bench.py --no-build --config n1270_5r --steps 100 --warmup 5 --require-roofline > $O/bench_n1270_5r.json 2>> $O/bench.err
+python bench.py --no-build --config n1270_coarse --steps 100 --warmup 5 --require-roofline > $O/bench_n1270_coarse.json 2>> $O/bench.err
+python bench.py --no-build --config osd_bp4_minsum --steps 20 --warmup 3 --require-roofline > $O/bench_osd_bp4_minsum.json 2>> $O/bench.err
 python bench.py --no-build --config qldpc_882 --steps 100 --warmup 5 --require-roofline > $O/bench_qldpc_882.json 2>> $O/bench.err
 python bench.py --no-build --config qldpc_1270 --steps 100 --warmup 5 --require-roofline > $O/bench_qldpc_1270.json 2>> $O/bench.err
 cat $O/bench_c3.json

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Re-measure what bench.py's rooflines quote from profiles/traffic.json (HBM bytes, VALU / MFMA instruction counts per launch of the
 # dominant kernels of BASELINE configs[2], [3] and [4] at their per-GPU shard shapes) after a kernel source changed:
-#     bash tools/refresh_traffic.sh <tag> [c1 c1phi c3 c4 c5 n882 n1270 q882 q1270]        (c2 = the first launch of c3: no pass of its own)
+#     bash tools/refresh_traffic.sh <tag> [c1 c1phi c3 c4 c5 n882 n1270 q882 q1270 osdms]        (c2 = the first launch of c3: no pass of its own)
 # Four rocprofv3 --pmc passes per configuration (~20-40 s each) on the GPU box; writes the summaries and the regenerated traffic.json into
 # gpurun_out/<tag>/ (then: cp gpurun_out/<tag>/traffic.json profiles/traffic.json; cp gpurun_out/<tag>/*pmc_summary.txt profiles/).
 set -e
@@ -20,6 +20,7 @@ for cfg in $CONFIGS; do
     c1phi) PROG="tools/prof_kernels.py ghp882 256 fixed 32 0.05 boxplus-phi 0.625"; SPEC="sandwich:ghp882:256:32";;     # the QLDPC.ipynb cell 11 variant
     n882) PROG="tools/prof_kernels.py ghp882 5000 fixed 64,16 0.05"; SPEC="sandwich:ghp882:5000:64";;                  # the published workloads' batch (n882.py:39)
     n1270) PROG="tools/prof_kernels.py ghp1270 5000 fixed 64,16 0.07"; SPEC="sandwich:ghp1270:5000:64";;
+    osdms) PROG="tools/prof_kernels.py ghp882 50000 fixed 120 0.09 minsum 0.8"; SPEC="sandwich:ghp882:50000:120:minsum";;   # OSD.ipynb cell 6
     q882) PROG="tools/prof_kernels.py ghp882 10000 fixed 64 0.01 boxplus-phi 0.8"; SPEC="sandwich:ghp882:10000:64";;     # QLDPC.ipynb cell 12: batch 10 000
     q1270) PROG="tools/prof_kernels.py ghp1270 10000 fixed 64 0.01 boxplus-phi 0.8"; SPEC="sandwich:ghp1270:10000:64";;
     c3) PROG="tools/prof_kernels.py ghp882 65536 fixed 64,16"; SPEC="sandwich:ghp882:65536:64";;
