@@ -27,14 +27,17 @@ the reference's fixed dataflow; the shortcut / compaction variants (bit-identica
 sharded over ranks by global sample index with no data-path collective; the three counters are all-reduced once at the end ("weak"
 scaling: per-GPU batch fixed).
 
-WHICH ARITHMETIC IS TIMED.  `value` is measured on the library's default operation sequence: the two re-associations that remove
-redundancy of the reference's own formulas (the qubit update's log-sum-exp term shared per qubit side, the GNNs' factored Dense layers:
-DESIGN.md §3) are ON — `config` names them.  The same step with the reference's formulas term by term (decoding_q.py:254-273 one
-log-sum-exp per edge, feedback_gnn.py:175-184 / gnn.py:573-610 one Dense per edge) is timed in the same run and reported at top level as
-`literal_forms` {value, ms_per_step}; `forms_agreement` decodes the first timed batch under both and reports, per sample, how many final
-decisions differ and how far the marginals are apart (north-star bar: decisions identical, LLRs within 1e-4) — at p = 0.01 the two are
-the same decoder sample by sample, in the waterfall (p >= 0.03) they are the same decoder statistically (include/fgnn.h).
-FGNN_BENCH_BP4_LSE=literal / FGNN_BENCH_GNN_ORDER=literal make the literal forms the headline.
+WHICH ARITHMETIC IS TIMED.  `value` is measured on the library's default operation sequence, which since round 6 is the reference's
+formulas term by term: one reduce_logsumexp per edge in the qubit update (decoding_q.py:254-273) and one 40 -> 20 Dense per edge in the
+feedback GNN (feedback_gnn.py:175-184 / gnn.py:573-610) — `config` names them (`gnn_association: literal`, `bp4_qubit_update_lse: per edge
+(literal)`), and `literal_forms` repeats the figure under the key earlier rounds used.  The two OPT-IN re-associations (include/fgnn.h
+options 4 and 5: the log-sum-exp term shared per qubit side, the GNNs' Dense layers factored; the same real-number functions, statistically
+the same decoder, NOT the reference's operation sequence) are timed in the same run on single-GPU runs and reported under
+`extras.reassociated_forms` {value, ms_per_step, forms_agreement} next to the opt-in hardware-transcendental variant; `forms_agreement`
+decodes the first timed batch under both and reports, per sample, how many final decisions differ and how far the marginals are apart
+(north-star bar: decisions identical, LLRs within 1e-4 — which the re-associated forms do NOT meet on every sample: DESIGN.md §3).
+FGNN_BENCH_BP4_LSE=shared / FGNN_BENCH_GNN_ORDER=factored make the re-associated forms the timed headline (A/B and profiling runs only;
+`value_is` then says so).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against the bound it is actually subject to.  c3 / c4: the
 64-iteration BP4 launch, bound by VALU instruction issue — it keeps every message in LDS for all iterations, so HBM sees only its
@@ -42,7 +45,7 @@ inputs and outputs (0.4 % of peak) and the MFMA pipe nothing; `achieved` = VALU 
 duration, measured live with HIP events recorded on the launch stream around every launch of the timed region (fgnn_profile_*);
 `peak` = 1 024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; `frac` = achieved / peak <= 1.  That is issue UTILISATION of the
 library's own instruction stream; next to it stands the algorithmic reading: `transcendental_evals_per_launch` (every exp and log the
-fixed dataflow evaluates: 16 + 28 per qubit-iteration in the shared form) / launch time against the chip's quarter-rate hardware
+fixed dataflow evaluates: 20 + 32 per qubit-iteration in the literal form) / launch time against the chip's quarter-rate hardware
 transcendental rate (1 024 SIMDs x 64 lanes x 2.4 GHz / 8 = 1.97e13 /s) = `frac_of_hw_transcendental_rate` — what a bit-inexact
 v_exp_f32 / v_log_f32 implementation is bounded by.  c5: the GNN_BP4 launch against the f32 MFMA (= f32 vector) peak in the reference's
 FLOPs.  The instruction counts / HBM bytes per launch are properties of the compiled kernel at a shape (fixed dataflow:
@@ -165,6 +168,18 @@ def gnnbp4_flops_per_codeword_factored(n, m, E, iters, D=20, H=40):
     return iters * vn + iters * cn
 
 
+def pmc_key(kind, code_name, B, iters=None, cn_type="boxplus-phi", reassociated=False):
+    """Key of profiles/traffic.json: kernel kind, code, launch shape, check-node rule when it is not 'boxplus-phi', and the FORM the PMC
+    pass ran: no suffix = the library default (the reference's formulas term by term), `_shared` / `_factored` = the opt-in re-association
+    of that kernel (tools/refresh_traffic.sh configurations c3r / c4r)."""
+    key = f"{kind}_{code_name}" + (f"_it{iters}" if iters is not None else "") + f"_B{B}"
+    if kind == "bp4" and cn_type != "boxplus-phi":
+        key += f"_{cn_type}"
+    if reassociated:
+        key += "_shared" if kind == "bp4" else "_factored"
+    return key
+
+
 def pmc_entry(kind, key):
     """The offline rocprofv3 counts of one kernel at one shape from profiles/traffic.json, or (None, reason) when there is none
     or when the kernel's sources have changed since they were taken (a count of some other build is not a measurement of this one)."""
@@ -219,9 +234,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-build", action="store_true",
                     help="do not run make: only check that the libraries exist (profiled runs, child ranks)")
-    ap.add_argument("--no-literal", action="store_true",
-                    help="skip the literal-forms timing and the forms_agreement decode (profiled runs: the literal BP4 launches are the same "
-                         "kernel symbol with a runtime flag and would be averaged into the trace's per-kernel statistics)")
+    ap.add_argument("--no-literal", "--no-other-forms", dest="no_literal", action="store_true",
+                    help="skip the timing of the other forms (the opt-in re-associations on a default run) and the forms_agreement decode "
+                         "(profiled runs: only the launches of the warm-up and of the timed region reach the trace)")
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="untimed GPU work (an elementwise torch loop, none of this library's kernels) before the warm-up steps, in ms of wall time")
     ap.add_argument("--cpu-legs-to", default=None, help=argparse.SUPPRESS)  # internal: run the CPU legs only and pickle them to this path
@@ -344,9 +359,9 @@ def cpu_legs(args, code, wname, iters, seed, factored):
     L0 = llr_const(args.p0)
     w = read_weight_list(wname)
     cpu_model = _cpu_model()
-    shared = os.environ.get("FGNN_BENCH_BP4_LSE", "shared") != "literal"
+    shared = os.environ.get("FGNN_BENCH_BP4_LSE", "literal") == "shared"
     # the checker restates the very forms the GPU run is configured with (both restatements exist in oracle/fgnn_oracle.c)
-    og = OracleGraph(code, forms="library-default" if (factored and shared) else "literal")
+    og = OracleGraph(code, forms="reassociated" if (factored and shared) else "literal")
     og.set_gnn_order(factored)
     og.set_vn_shared_lse(shared)
     nl = len(iters)
@@ -437,7 +452,7 @@ def cpu_legs_c5(args, code, weights, num_iter, seed, factored):
     if "OMP_NUM_THREADS" not in os.environ:
         set_num_threads(share)
     cpu_model = _cpu_model()
-    og = OracleGraph(code, forms="library-default" if factored else "literal")
+    og = OracleGraph(code, forms="reassociated" if factored else "literal")
     og.set_gnn_order(factored)
     if args.cpu_baseline in ("both", "port"):
         S = args.cpu_sample
@@ -498,9 +513,7 @@ def gnnbp4_roofline(code_name, dims, launches, B, num_iter, factored):
     dom_ms = float(np.mean(dom)) if dom else None
     flops = gnnbp4_flops_per_codeword(n, m, E, num_iter) * B
     tf = flops / (dom_ms * 1e-3) / 1e12 if dom_ms else None
-    ent, tsrc = pmc_entry("gnnbp4", f"gnnbp4_{code_name}_it{num_iter}_B{B}")
-    if ent and not factored:
-        ent, tsrc = None, "profiles/traffic.json holds the counts of the default (factored) association; this run times the literal one"
+    ent, tsrc = pmc_entry("gnnbp4", pmc_key("gnnbp4", code_name, B, num_iter, reassociated=factored))
     traffic = ent.get("hbm_bytes_per_launch") if ent else None
     vi = ent.get("valu_wave_insts_per_launch") if ent else None
     mi = ent.get("mfma_insts_per_launch") if ent else None
@@ -538,9 +551,7 @@ def feedback_gnn_roofline(code_name, dims, launches, B, factored, stream):
     gnn_flops = gnn_flops_per_codeword(n, E) * B
     gnn_exec = (gnn_flops_per_codeword_factored(n, E) if factored else gnn_flops_per_codeword(n, E)) * B
     gnn_tf = gnn_flops / (gnn_ms * 1e-3) / 1e12 if gnn_ms else None
-    gent, gsrc = pmc_entry("gnn", f"gnn_{code_name}_B{B}")
-    if gent and not factored:
-        gent, gsrc = None, "profiles/traffic.json holds the counts of the default (factored) association; this run times the literal one"
+    gent, gsrc = pmc_entry("gnn", pmc_key("gnn", code_name, B, reassociated=factored))
     gvi = gent.get("valu_wave_insts_per_launch") if gent else None
     entry_is_of_the_mfma_kernel = bool(gent and gent.get("mfma_insts_per_launch"))  # the streaming kernel issues no MFMA
     if gent and entry_is_of_the_mfma_kernel == stream:
@@ -551,6 +562,11 @@ def feedback_gnn_roofline(code_name, dims, launches, B, factored, stream):
               "executed_frac": gnn_exec / (gnn_ms * 1e-3) / 1e12 / GNN_PEAK_TFLOPS if gnn_ms else None,
               "traffic": gent.get("hbm_bytes_per_launch") if gent else None,
               "mfma_insts_per_launch": gent.get("mfma_insts_per_launch") if gent else None,
+              # MFMA-busy of this launch: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs-worth of cycles is what the counter sums over) — 0 on the
+              # streaming VALU kernel, which issues no MFMA at all (an f32 MFMA shares the FP32 lanes on gfx950: DESIGN.md §4.2)
+              "mfma_busy_cycles_per_launch": gent.get("mfma_busy_cycles") if gent else None,
+              "mfma_busy_frac": (gent.get("mfma_busy_cycles") / (1024 * 2.4e9 * gnn_ms * 1e-3)
+                                 if (gent and gent.get("mfma_busy_cycles") is not None and gnn_ms) else None),
               "valu_wave_insts_per_launch": gvi, "traffic_source": gsrc}
     if stream:
         # the default: factored association on the streaming VALU kernel (no MFMA: on gfx950 an f32 MFMA has the f32 VALU's rate and
@@ -586,9 +602,7 @@ def sandwich_roofline(code_name, dims, launches, launches_per_step, B, iters, fa
     # VALU instruction counts and HBM bytes per launch are NOT measured by this run: they come from the rocprofv3 PMC passes of
     # tools/refresh_traffic.sh at the same shape, guarded by the fingerprint of the kernel sources (pmc_entry)
     # one entry per check-node rule (a template argument of the kernel); the normalization factor is a runtime multiplier
-    ent, tsrc = pmc_entry("bp4", f"bp4_{code_name}_it{iters[0]}_B{B}" + ("" if cn_type == "boxplus-phi" else f"_{cn_type}"))
-    if ent and not shared_lse:
-        ent, tsrc = None, "profiles/traffic.json holds the counts of the default (shared log-sum-exp) form; this run times the literal form"
+    ent, tsrc = pmc_entry("bp4", pmc_key("bp4", code_name, B, iters[0], cn_type, reassociated=shared_lse))
     traffic = ent.get("hbm_bytes_per_launch") if ent else None
     vi = ent.get("valu_wave_insts_per_launch") if ent else None
     achieved = vi / (dom_ms * 1e-3) / 1e9 if (vi and dom_ms) else None
@@ -600,6 +614,11 @@ def sandwich_roofline(code_name, dims, launches, launches_per_step, B, iters, fa
             "frac": achieved / VALU_PEAK_GINST if achieved else None,
             "traffic": traffic, "traffic_source": tsrc,
             "valu_wave_insts_per_launch": vi,
+            # the BP4 kernel issues no MFMA (north_star: "MFMA used only for the dense per-node MLP of the feedback GNN"): SQ_INSTS_MFMA of the
+            # same PMC pass, and the MFMA pipe's busy cycles over the launch's SIMD cycles
+            "mfma_insts_per_launch": ent.get("mfma_insts_per_launch") if ent else None,
+            "mfma_busy_frac": (ent.get("mfma_busy_cycles") / (1024 * 2.4e9 * dom_ms * 1e-3)
+                               if (ent and ent.get("mfma_busy_cycles") is not None and dom_ms) else None),
             "library_is_the_profiled_binary": ent.get("library_is_the_profiled_binary") if ent else None,
             "avg_launch_ms": dom_ms, "launches_timed": len(dom),
             "later_decoders_avg_launch_ms": float(np.mean(later)) if later else None,
@@ -652,7 +671,7 @@ def gnnbp4_forms_agreement(g, wdev, sx, sz, num_iter, workspace):
             "max_abs_dllr": float(d.max()), "samples_gt_1e_4": int((d > 1e-4).sum())}
 
 
-def sandwich_extras(g, model, code, decs, G, iters, B, p, seed, literal_value, cn_type="boxplus-phi", factor=1.0, p0=0.05):
+def sandwich_extras(g, model, code, decs, G, iters, B, p, seed, cn_type="boxplus-phi", factor=1.0, p0=0.05):
     """`extras` of a single-GPU c3 / c4 run: the variants that are NOT the headline — BP4 alone (configs[1]), the product default (exact
     shortcuts, compaction: identical outputs) and the opt-in hardware-transcendental BP4 with its measured distance from the exact kernel."""
     import numpy as np
@@ -728,8 +747,7 @@ def sandwich_extras(g, model, code, decs, G, iters, B, p, seed, literal_value, c
             "sandwich_compacted_cw_per_s (feedback rounds only on flagged samples, same outputs)": B / t_c,
             "sandwich_compacted_product_default_cw_per_s (all exact optimisations, same outputs)": B / t_cs,
             "sandwich_two_streams_cw_per_s (fixed dataflow, Sandwich_BP_GNN_Evaluation_Model(streams=2): consecutive batches alternate between two "
-            "HIP streams; same samples, same counters)": B / t_2s,
-            "sandwich_literal_forms_cw_per_s (now the top-level literal_forms object)": literal_value}
+            "HIP streams; same samples, same counters)": B / t_2s}
 
 
 def main():
@@ -755,11 +773,12 @@ def main():
     iters = [int(x) for x in args.iters.split(",")]
     code, wname = make_code(args.code)
     wname = CONFIGS[args.config].get("weights", wname)  # (n1270_coarse: the coarse GNN of n1270.ipynb cell 9)
-    factored = os.environ.get("FGNN_BENCH_GNN_ORDER", "factored") != "literal"  # the library default; "literal" times the other order
+    # the library default = the reference's association (one Dense per edge); FGNN_BENCH_GNN_ORDER=factored times the opt-in re-association
+    factored = os.environ.get("FGNN_BENCH_GNN_ORDER", "literal") == "factored"
     # both associations run on the streaming VALU kernel by default (the library's choice at these batch sizes);
     # FGNN_BENCH_GNN_KERNEL=mfma times the MFMA-tile kernel
     stream = os.environ.get("FGNN_BENCH_GNN_KERNEL", "stream") != "mfma"
-    shared_lse = os.environ.get("FGNN_BENCH_BP4_LSE", "shared") != "literal"    # likewise for the qubit update's log-sum-exp term
+    shared_lse = os.environ.get("FGNN_BENCH_BP4_LSE", "literal") == "shared"    # likewise for the qubit update's log-sum-exp term
     c5_weights = gnnbp4_seeded_weights(0) if is_c5 else None
 
     # ---- CPU baselines first (rank 0 of a single-GPU run), in a CHILD interpreter: its OpenMP / torch intra-op / BLAS thread pools end
@@ -861,6 +880,7 @@ def main():
     lib()  # fail loudly if the HIP extension is missing
 
     B, K, W = args.batch, args.steps, args.warmup
+    sample_log = []  # [first, last) of the global Philox sample range of every step this rank has run, in order
     if is_c5:
         from feedback_gnn_amd.graph import TannerGraph
         g = TannerGraph(code)
@@ -879,6 +899,7 @@ def main():
         def step(counts):
             first = state["next"] + rank * B
             state["next"] += world * B
+            sample_log.append((first, first + B))
             o = c5_decode(first)
             _, _, flags = g.residual(o["noise_x"], o["noise_z"], o["x_hat"], o["z_hat"], want_arrays=False)
             g.count_flags(flags, counts)
@@ -907,6 +928,8 @@ def main():
         model = make_model(args.streams)
 
         def step(counts):
+            first = model.next_sample_range(B)[0]
+            sample_log.append((first, first + B))
             model.mc_step(B, args.p, counts)
 
         launches_per_step = 2 * len(iters) - 1  # BP4 launches + feedback-GNN launches
@@ -956,27 +979,47 @@ def main():
         warm = torch.zeros(3, dtype=torch.int64, device="cuda")
         for _ in range(W):
             step(warm)
+        n_before = len(sample_log)
         elapsed, own_elapsed, launches, counts = timed_region(K, True)
+        timed_ranges = sample_log[n_before:]
+        own_counts = [int(v) for v in counts.cpu().numpy()]  # this rank's counters before the all-reduce
         per_rank_ms = [own_elapsed / K * 1e3]
+        rank_rows = [[rank, timed_ranges[0][0], timed_ranges[-1][1]] + own_counts]
         if dist is not None:
             per_rank_ms = [float(v) for v in allgather(torch.tensor([own_elapsed / K * 1e3], dtype=torch.float64, device="cuda")).flatten()]
+            # every rank's timed sample range and its own counters (int64: [rank, first, last, flagged, block_errors, samples]), by the same
+            # all-gather path as the step times, and the per-step ranges, so that rank 0 can prove the sharding (below)
+            rank_rows = allgather(torch.tensor(rank_rows[0], dtype=torch.int64, device="cuda")).cpu().numpy().tolist()
+            step_ranges = allgather(torch.tensor(timed_ranges, dtype=torch.int64, device="cuda")).cpu().numpy().tolist()
             counts = allreduce(counts, dist.ReduceOp.SUM)
-        # ---- the same step with the reference's formulas term by term (both re-associations off), every rank, same bracket ----
-        literal = None
-        if (factored or (shared_lse and not is_c5)) and not args.no_literal:
-            g.set_gnn_factored(False)
+        else:
+            step_ranges = [[list(r) for r in timed_ranges]]
+        # ---- the same step under the OTHER forms (single-GPU runs): the opt-in re-associations when the headline is the library
+        # default, the literal forms when an A/B run made the re-associated ones the headline; same bracket, same sample stream ----
+        other_forms = None
+        headline_is_literal = not factored and (is_c5 or not shared_lse)
+        if world == 1 and not args.no_literal and (headline_is_literal or factored or shared_lse):
+            to_reassociated = headline_is_literal
+            g.set_gnn_factored(to_reassociated)
             if not is_c5:
-                g.set_bp4_shared_lse(False)
+                g.set_bp4_shared_lse(to_reassociated)
             step(torch.zeros(3, dtype=torch.int64, device="cuda"))  # untimed: first launch of these kernel variants
-            lit_elapsed, _, _, _ = timed_region(K, False)
+            o_elapsed, _, _, _ = timed_region(K, False)
             g.set_gnn_factored(factored)
             if not is_c5:
                 g.set_bp4_shared_lse(shared_lse)
-            literal = {"value": world * B * K / lit_elapsed, "unit": "codewords/s", "ms_per_step": lit_elapsed / K * 1e3, "steps": K,
-                       "what": "the same step, same samples stream, with the reference's formulas term by term: "
-                               + ("GNN_BP4 message MLP once per edge (gnn.py:573-610, 714-751), FGNN_OPT_GNN_FACTORED = 0" if is_c5 else
-                                  "one log-sum-exp per edge in the qubit update (decoding_q.py:254-273, FGNN_OPT_BP4_SHARED_LSE = 0) and one "
-                                  "40 -> 20 Dense per edge in the feedback GNN (feedback_gnn.py:175-184, FGNN_OPT_GNN_FACTORED = 0)")}
+            other_forms = {"value": world * B * K / o_elapsed, "unit": "codewords/s", "ms_per_step": o_elapsed / K * 1e3, "steps": K,
+                           "forms": "re-associated (opt-in)" if to_reassociated else "literal",
+                           "what": ("the same step, same sample stream, with the two OPT-IN re-associations on: "
+                                    + ("GNN_BP4 message MLP factored (FGNN_OPT_GNN_FACTORED = 1)" if is_c5 else
+                                       "the qubit update's log-sum-exp term once per qubit and side (FGNN_OPT_BP4_SHARED_LSE = 1) and the "
+                                       "feedback GNN's Dense layers factored (FGNN_OPT_GNN_FACTORED = 1)")
+                                    + " — the same real-number functions, statistically the same decoder, NOT the reference's float32 "
+                                      "operation sequence (see forms_agreement)") if to_reassociated else
+                                   ("the same step, same sample stream, with the reference's formulas term by term (the library default): "
+                                    + ("GNN_BP4 message MLP once per edge (gnn.py:573-610, 714-751)" if is_c5 else
+                                       "one log-sum-exp per edge in the qubit update (decoding_q.py:254-273) and one 40 -> 20 Dense per edge "
+                                       "in the feedback GNN (feedback_gnn.py:175-184)"))}
         # ---- the reference's published workloads run 5 000-codeword batches (n882.py:39): one such batch fills a fraction of the chip,
         # so the same step is also timed with consecutive batches alternating between two HIP streams (same samples, same counters)
         other_streams = None
@@ -1054,13 +1097,12 @@ def main():
                 "roofline": sandwich_roofline(args.code, (n, m, E), launches, launches_per_step, B, iters, factored, stream, shared_lse,
                                               args.cn_type),
                 "counts": counts_obj})
-        if literal is not None:
-            out["literal_forms"] = literal
-        elif args.no_literal:
-            out["literal_forms"] = None
-        else:
-            out["literal_forms"] = {"value": value, "ms_per_step": elapsed / K * 1e3, "unit": "codewords/s",
-                                    "what": "the headline of this run IS the literal forms (FGNN_BENCH_BP4_LSE / FGNN_BENCH_GNN_ORDER = literal)"}
+        headline = {"value": value, "ms_per_step": elapsed / K * 1e3, "unit": "codewords/s", "steps": K}
+        if headline_is_literal:
+            out["literal_forms"] = dict(headline, what="the headline of this run IS the literal forms: the reference's formulas term by term are "
+                                                       "the library default (`value` repeated under the key of earlier rounds)")
+        else:  # an A/B run with FGNN_BENCH_BP4_LSE=shared / FGNN_BENCH_GNN_ORDER=factored
+            out["literal_forms"] = other_forms
         if args.streams > 1 and not is_c5:
             # launches of consecutive batches overlap on the chip, so a HIP-event bracket around one launch also covers its neighbour's
             # work: the per-launch durations (and every fraction priced with them) are not this kernel's own — say so instead of quoting them
@@ -1076,15 +1118,32 @@ def main():
         out["dist"] = dist_info
         if other_streams is not None:
             out["two_streams" if other_streams["streams"] == 2 else "one_stream"] = other_streams
-        out["value_is"] = ("the library's default operation sequence (two re-associations of the reference's formulas on: identical decisions to the "
-                           "literal forms on every sample of a 65 536-codeword batch at p <= 0.02 (3 of 8.4 M at p = 0.01), statistically the same decoder in the waterfall — see forms_agreement at "
-                           "this run's p); literal_forms.value is the same step with the reference's formulas term by term"
-                           if (factored or (shared_lse and not is_c5)) else "the reference's formulas term by term (literal forms)")
+        out["value_is"] = ("the reference's formulas term by term (literal forms), the library's default operation sequence: one log-sum-exp per edge "
+                           "(decoding_q.py:254-273), one Dense per edge (feedback_gnn.py:175-184 / gnn.py:573-610); extras.reassociated_forms is the "
+                           "same step under the two opt-in re-associations" if headline_is_literal else
+                           "AN A/B RUN, not the library default: the opt-in re-associated forms named in `config` (FGNN_BENCH_BP4_LSE / "
+                           "FGNN_BENCH_GNN_ORDER); literal_forms.value is the same step with the reference's formulas term by term")
+        # ---- multi-GPU proof of the sharding (no 8-GPU node needed to test it: gloo world 2-3 in tests/test_bench_contract.py): every rank's
+        # timed sample range and own counters; the per-step ranges of all ranks must tile [W*world*B, (W+K)*world*B) without overlap, and the
+        # ranks' own counters must add up to the all-reduced ones
+        for row in out["dist"]["ranks"]:
+            rr = [r for r in rank_rows if r[0] == row["rank"]][0]
+            row["timed_samples"] = [int(rr[1]), int(rr[2])]
+            row["own_counts"] = {"flagged": int(rr[3]), "block_errors": int(rr[4]), "samples": int(rr[5])}
+        flat = sorted((int(a), int(b)) for per_rank in step_ranges for a, b in per_rank)
+        lo, hi = W * world * B, (W + K) * world * B
+        tiles = (len(flat) == world * K and flat[0][0] == lo and flat[-1][1] == hi
+                 and all(flat[i][1] == flat[i + 1][0] for i in range(len(flat) - 1)) and all(b - a == B for a, b in flat))
+        sums = [sum(int(r[3 + j]) for r in rank_rows) for j in range(3)]
+        out["dist"]["sharding"] = {"timed_region_samples": [lo, hi], "batches": len(flat),
+                                   "ranges_tile_the_region_without_overlap": bool(tiles),
+                                   "sum_of_rank_counts": {"flagged": sums[0], "block_errors": sums[1], "samples": sums[2]},
+                                   "sum_of_rank_counts_equals_all_reduced": sums == [int(cnt[0]), int(cnt[1]), int(cnt[2])]}
+        sharding_ok = tiles and sums == [int(cnt[0]), int(cnt[1]), int(cnt[2])]
 
-    if rank == 0 and args.no_literal:
-        out["forms_agreement"] = None
-    elif rank == 0:
-        # ---- per-sample agreement of the default forms with the literal ones on the first batch of the timed region ----
+    fa = None
+    if rank == 0 and world == 1 and not args.no_literal:
+        # ---- per-sample agreement of the opt-in re-associated forms with the literal ones on the first batch of the timed region ----
         first_timed = W * world * B  # rank 0's first timed batch starts at global sample W * world * B
         ex, ez = g.pauli_noise(SEED, args.p, first_timed, B)
         sx, sz = g.syndrome(ex, ez)
@@ -1094,14 +1153,14 @@ def main():
             fa = g.forms_agreement(sx, sz, iters, [G.device_weights] * (len(iters) - 1), llr_const(args.p0),
                                    factors=[args.factor] * len(iters), cn_types=[args.cn_type] * len(iters))
         fa["p"] = args.p
-        fa["what"] = ("the first timed batch of rank 0 decoded under the default forms and under the literal forms (both this library's "
-                      "kernels, each bit-equal to the oracle's restatement of its form): samples whose final decisions differ, max over "
+        fa["first_sample"] = first_timed
+        fa["what"] = ("the first timed batch of rank 0 decoded under the opt-in re-associated forms and under the literal forms (both this "
+                      "library's kernels, each bit-equal to the oracle's restatement of its form): samples whose final decisions differ, max over "
                       "samples of max |dLLR| of the last decoder's marginals, samples beyond the north-star tolerance 1e-4"
                       + ("; decisions_differ_beyond_llr_tolerance = samples with a qubit that decides differently although its two best "
                          "candidates of argmin(0, X, Z, Y) are more than 2e-4 apart (the seeded, untrained weights leave many marginals within "
                          "1e-5 of the decision boundary, where a 1e-6 rounding difference flips the argmin)" if is_c5 else "; *_solved = over the samples neither form leaves flagged (a sample BP does not converge on is "
                                           "chaotic under any change of float32 rounding); first_decoder = the BP4-64 launch alone"))
-        out["forms_agreement"] = fa
 
     # ---- extras and the equality check of the CPU sample: rank 0, single-GPU runs only, bounded time, all GPU work ----
     if rank == 0 and world == 1:
@@ -1125,8 +1184,19 @@ def main():
         if "cpu_baseline_tf_like" in out:
             out["speedup_vs_cpu_tf_like"] = value / out["cpu_baseline_tf_like"]["value"]
         if not args.no_extras and not is_c5:
-            out["extras"] = sandwich_extras(g, model, code, decs, G, iters, B, args.p, SEED, (out["literal_forms"] or {}).get("value"),
-                                            args.cn_type, args.factor, args.p0)
+            out["extras"] = sandwich_extras(g, model, code, decs, G, iters, B, args.p, SEED, args.cn_type, args.factor, args.p0)
+        elif not args.no_extras:
+            out["extras"] = {}
+        if "extras" in out:
+            # the opt-in re-associated forms (NOT the reference's operation sequence) next to the other opt-in variants, with their agreement
+            if headline_is_literal and other_forms is not None:
+                out["extras"]["reassociated_forms"] = dict(other_forms, forms_agreement=fa, speedup_vs_value=other_forms["value"] / value)
+            elif fa is not None:
+                out["extras"]["forms_agreement (this A/B run's re-associated headline vs the literal forms)"] = fa
+        elif other_forms is not None and headline_is_literal:  # --no-extras: keep the figure, under its own key
+            out["reassociated_forms"] = dict(other_forms, forms_agreement=fa)
+        elif args.no_literal:
+            out["reassociated_forms"] = None  # --no-literal / --no-other-forms: not timed, and the line says so
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
@@ -1137,6 +1207,9 @@ def main():
             dist.barrier()
         finally:
             dist.destroy_process_group()
+    if rank == 0 and not sharding_ok:
+        sys.stderr.write(f"bench.py: the ranks' timed sample ranges do not tile the timed region or their counters do not add up: {out['dist']['sharding']}\n")
+        sys.exit(8)
     if rank == 0 and args.require_roofline and out["roofline"].get("frac") is None:
         sys.stderr.write(f"bench.py: --require-roofline: roofline.frac is null ({out['roofline'].get('traffic_source')})\n")
         sys.exit(5)

@@ -81,6 +81,7 @@ _SIGNATURES = {
     "fgnn_weights_destroy": (None, [C.c_void_p]),
     "fgnn_feedback_gnn": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_void_p]),
     "fgnn_pauli_noise": (C.c_int, [C.c_uint64, C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fgnn_pauli_noise_xyz": (C.c_int, [C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fgnn_pauli_noise_wt": (C.c_int, [C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fgnn_pauli_noise_dev": (C.c_int, [C.c_uint64, C.c_float, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fgnn_syndrome": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -133,9 +134,15 @@ def lib():
         # brought into the process (same soname), which is what makes torch's device pointers and streams
         # valid inside libfgnn_hip.so.  Loading the library before torch would start a second runtime.
         import torch  # noqa: F401
-        L = C.CDLL(os.environ.get("FGNN_LIB_PATH", LIB_PATH))  # override: A/B builds of the same ABI (tools/)
+        override = os.environ.get("FGNN_LIB_PATH")  # A/B builds of the same ABI (tools/)
+        L = C.CDLL(override or LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(L, name)
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                if override:  # an A/B build of an older tree may predate an entry point; the shipped library must export them all
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = L

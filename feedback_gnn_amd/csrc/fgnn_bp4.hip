@@ -32,6 +32,9 @@
 #ifndef FGNN_PHI_STAGE
 #define FGNN_PHI_STAGE 1  // phi evaluations staged together in the regular check-node update (phi_n), must divide DC
 #endif
+#ifndef FGNN_LSE_STAGE
+#define FGNN_LSE_STAGE 0  // literal qubit update of the regular kernel: 0 = one fg_lse2 per edge in turn, 1 = the edges of a side staged (lse2_n)
+#endif
 
 namespace {
 
@@ -279,6 +282,49 @@ __device__ __forceinline__ void phi_n(const float (&x)[N], float (&out)[N])
     }
 }
 
+// N evaluations of fg_lse2 (fgnn_math.h) — the per-edge reduce_logsumexp of the LITERAL qubit update (decoding_q.py:266, :271) — laid
+// out like phi_n: (A) |a - b|, the clamp, exp, 1 + y and the table address of every value; (B) the N two-dword table reads; (C) the
+// remainders, polynomials and the + max(a, b).  Every value goes through exactly the float operations of fg_lse2 in the same order:
+// -min(d, 20) is formed as max(-d, -20) (the same float) and made opaque to the compiler, so that the exponential's range reduction
+// issues as full-rate VOP2 literal forms instead of a VOP3 with a negated source and the constant in an SGPR (half rate on gfx950).
+template <int N, bool HWT = false>
+__device__ __forceinline__ void lse2_n(const float (&a)[N], const float (&b)[N], float (&out)[N])
+{
+    if constexpr (HWT) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) out[k] = Mx<true>::lse2(a[k], b[k]);
+        return;
+    }
+    const float* tab = fg_log_tab();
+    float x1[N];
+    uint32_t eb[N], j[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        float nd = FG_MAX(-FG_ABS(a[k] - b[k]), -20.0f);  // = -min(|a - b|, 20)
+        asm volatile("" : "+v"(nd));
+        const float y = fg_exp(nd);
+        x1[k] = 1.0f + y;
+        const uint32_t w = fg_f2u(x1[k]) - FG_LOG_OFFS;  // fg_log(1 + y)
+        eb[k] = w & 0xff800000u;
+        j[k] = (w >> 18) & 31u;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float rc[N], lc[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        rc[k] = tab[j[k]];
+        lc[k] = tab[32 + j[k]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float mm = fg_u2f(fg_f2u(x1[k]) - eb[k]);
+        const float r = FG_FMA(mm, rc[k], -1.0f);
+        const float lg = FG_FMA((float)(int32_t)eb[k], FG_LN2_S23, lc[k] + fg_log1p_small(r));
+        out[k] = lg + FG_MAX(a[k], b[k]);
+    }
+}
+
 // c->v update of one (DC-regular) check with every message in registers: the phi rule of the benchmark
 // configurations without the LDS round trip of the runtime-degree version.  Same float ops, same order.
 // Signs are carried as integer sign words: neg = (synd << 31) ^ bits(v_0) ^ ... (bit 31 = the parity of :398-399), and the
@@ -452,7 +498,10 @@ __device__ __forceinline__ float softplus_saturated(float t)
 // GMEM: the per-codeword state (messages, channel LLRs, epilogue scratch) lives in a global-memory workspace row instead of LDS — the
 // fallback for codes whose E + 3n floats exceed the CU's LDS (runtime degrees, fixed dataflow only).  Same float operations in the same
 // order; within a workgroup __syncthreads() orders the global stores of one phase before the loads of the next.
-template <int CN_TYPE, int DVX, int DVZ, int DC, bool OPT, bool HWT = false, int NQ = 0, bool TRACE = false, bool GMEM = false>
+// LSE: the form of the qubit update's log-sum-exp term — 0 = per edge (the reference's formulas term by term, decoding_q.py:254-273: the
+// library default), 1 = once per qubit and side (FGNN_OPT_BP4_SHARED_LSE), both compiled in for the (3,3,6)-regular phi kernels; 2 = either,
+// chosen by a.shared_lse at run time (every other instantiation).
+template <int CN_TYPE, int DVX, int DVZ, int DC, bool OPT, bool HWT = false, int NQ = 0, bool TRACE = false, bool GMEM = false, int LSE = 2>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NQ > 0 ? FGNN_BP4_WAVES - 1 : FGNN_BP4_WAVES)))
 bp4_kernel(GraphDev g, BpArgs a)
 {
@@ -465,7 +514,7 @@ bp4_kernel(GraphDev g, BpArgs a)
     constexpr int NQA = LREG ? NQ : 1;
     const bool opt_shortcut = OPT && a.shortcut != 0;
     const bool opt_exit = OPT && a.early_exit != 0;
-    const bool shl = a.shared_lse != 0;  // workgroup-uniform
+    const bool shl = LSE == 2 ? a.shared_lse != 0 : LSE == 1;  // workgroup-uniform; a compile-time constant for LSE = 0 / 1
     extern __shared__ float lds[];
     const int cwl = threadIdx.x / a.tpc;
     const int lane = threadIdx.x - cwl * a.tpc;
@@ -668,6 +717,20 @@ bp4_kernel(GraphDev g, BpArgs a)
                             const float Xe = X - mz[k], Ye = Y - mz[k];
                             pz[k] = numz - (cz + FG_MAX(-Xe, -Ye));
                         }
+                        return;
+                    }
+                    if constexpr (FGNN_LSE_STAGE != 0 && !HWT) {  // the edges of a side staged: same float operations, other schedule
+                        float ax[DVX], bx[DVX], ox[DVX], az[DVZ], bz[DVZ], oz[DVZ];
+#pragma unroll
+                        for (int k = 0; k < DVX; ++k) { ax[k] = -(Z - mx[k]); bx[k] = -(Y - mx[k]); }
+                        lse2_n<DVX>(ax, bx, ox);
+#pragma unroll
+                        for (int k = 0; k < DVX; ++k) px[k] = numx - ox[k];
+#pragma unroll
+                        for (int k = 0; k < DVZ; ++k) { az[k] = -(X - mz[k]); bz[k] = -(Y - mz[k]); }
+                        lse2_n<DVZ>(az, bz, oz);
+#pragma unroll
+                        for (int k = 0; k < DVZ; ++k) pz[k] = numz - oz[k];
                         return;
                     }
 #pragma unroll
@@ -927,8 +990,20 @@ int launch_bp4_k(const fgnn_graph* g, const BpArgs& a, const LaunchGeom& L, size
     if constexpr (CN_TYPE == FGNN_CN_BOXPLUS_PHI) {
         if (a.hwt) kern = bp4_kernel<CN_TYPE, DVX, DVZ, DC, false, true>;  // opt-in, fixed dataflow (fgnn_graph_set_option 3)
         if constexpr (DVX == 3 && DVZ == 3 && DC == 6) {
-            if (a.lreg == 4) kern = a.shortcut ? bp4_kernel<CN_TYPE, DVX, DVZ, DC, true, false, 4> : bp4_kernel<CN_TYPE, DVX, DVZ, DC, false, false, 4>;
-            if (a.lreg == 5) kern = a.shortcut ? bp4_kernel<CN_TYPE, DVX, DVZ, DC, true, false, 5> : bp4_kernel<CN_TYPE, DVX, DVZ, DC, false, false, 5>;
+            // the benchmark codes' kernels carry the form of the qubit update as a compile-time argument (LSE = 0 literal / 1 shared)
+            if (!a.trace_x && !a.hwt) {
+                const int v = (a.shortcut ? 1 : 0) | (a.shared_lse ? 2 : 0);
+                if (a.lreg == 4) {
+                    kern = v == 0 ? bp4_kernel<CN_TYPE, 3, 3, 6, false, false, 4, false, false, 0> : v == 1 ? bp4_kernel<CN_TYPE, 3, 3, 6, true, false, 4, false, false, 0>
+                         : v == 2 ? bp4_kernel<CN_TYPE, 3, 3, 6, false, false, 4, false, false, 1> : bp4_kernel<CN_TYPE, 3, 3, 6, true, false, 4, false, false, 1>;
+                } else if (a.lreg == 5) {
+                    kern = v == 0 ? bp4_kernel<CN_TYPE, 3, 3, 6, false, false, 5, false, false, 0> : v == 1 ? bp4_kernel<CN_TYPE, 3, 3, 6, true, false, 5, false, false, 0>
+                         : v == 2 ? bp4_kernel<CN_TYPE, 3, 3, 6, false, false, 5, false, false, 1> : bp4_kernel<CN_TYPE, 3, 3, 6, true, false, 5, false, false, 1>;
+                } else {
+                    kern = v == 0 ? bp4_kernel<CN_TYPE, 3, 3, 6, false, false, 0, false, false, 0> : v == 1 ? bp4_kernel<CN_TYPE, 3, 3, 6, true, false, 0, false, false, 0>
+                         : v == 2 ? bp4_kernel<CN_TYPE, 3, 3, 6, false, false, 0, false, false, 1> : bp4_kernel<CN_TYPE, 3, 3, 6, true, false, 0, false, false, 1>;
+                }
+            }
         }
     }
     if (lds_bytes > 48 * 1024)

@@ -15,14 +15,18 @@ namespace {
 // Pauli.call, sionna/channel/pauli.py:98-108.  One thread = 4 qubits of one sample (one Philox block).
 // `base` (optional, device): the stream position the launch starts from is *base + first — a hipGraph that replays a Monte-Carlo loop
 // keeps its position in device memory and advances it itself (fgnn_pauli_noise_dev), so every replay draws fresh samples.
-__global__ void __launch_bounds__(256) pauli_kernel(uint64_t seed, float p, uint64_t first, const unsigned long long* __restrict__ base,
-                                                    int B, int n, int nblk, uint8_t* __restrict__ ex, uint8_t* __restrict__ ez)
+// `thr_in` (optional): the thresholds of a general (px, py, pz) channel, formed on the host by fg_pauli_thresholds_xyz (additions and
+// subtractions only); without it the kernel forms the depolarizing split of `p` itself, as the oracle does.
+template <bool XYZ>
+__global__ void __launch_bounds__(256) pauli_kernel(uint64_t seed, float p, fg_pauli_thr thr_in, uint64_t first,
+                                                    const unsigned long long* __restrict__ base, int B, int n, int nblk,
+                                                    uint8_t* __restrict__ ex, uint8_t* __restrict__ ez)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)B * nblk) return;
     if (base) first += (uint64_t)*base;
     const int b = (int)(t / nblk), blk = (int)(t - (long long)b * nblk);
-    const fg_pauli_thr thr = fg_pauli_thresholds(p);
+    const fg_pauli_thr thr = XYZ ? thr_in : fg_pauli_thresholds(p);
     float u[4];
     fg_uniform4(seed, first + (uint64_t)b, (uint32_t)blk, u);
     const int q0 = blk * 4;
@@ -340,8 +344,26 @@ extern "C" int fgnn_pauli_noise(uint64_t seed, float p, uint64_t first_sample, i
     if (!noise_x || !noise_z) return fgnn_fail(FGNN_ERR_ARG, "bad noise arguments");
     const int nblk = (n + 3) / 4;
     const long long total = (long long)B * nblk;
-    hipLaunchKernelGGL(pauli_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), seed,
-                       p, first_sample, static_cast<const unsigned long long*>(nullptr), B, n, nblk, noise_x, noise_z);
+    hipLaunchKernelGGL(pauli_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), seed,
+                       p, fg_pauli_thr{0.0f, 0.0f, 0.0f}, first_sample, static_cast<const unsigned long long*>(nullptr), B, n, nblk,
+                       noise_x, noise_z);
+    FGNN_HIP_CHECK(hipGetLastError());
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_pauli_noise_xyz(uint64_t seed, float px, float py, float pz, uint64_t first_sample, int B, int n,
+                                    uint8_t* noise_x, uint8_t* noise_z, void* stream)
+{
+    // pauli.py:98-108 compares u with px, px - py and (px + pz) - py for ANY triple and validates nothing; only NaNs are refused here
+    // (X, Y and Z are the disjoint events of probability px - py, py, pz - py when 0 <= py <= min(px, pz) and px + pz - py <= 1)
+    if (B < 0 || n <= 0 || !(px == px && py == py && pz == pz)) return fgnn_fail(FGNN_ERR_ARG, "bad noise arguments");
+    if (B == 0) return FGNN_OK;
+    if (!noise_x || !noise_z) return fgnn_fail(FGNN_ERR_ARG, "bad noise arguments");
+    const int nblk = (n + 3) / 4;
+    const long long total = (long long)B * nblk;
+    hipLaunchKernelGGL(pauli_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), seed,
+                       0.0f, fg_pauli_thresholds_xyz(px, py, pz), first_sample, static_cast<const unsigned long long*>(nullptr), B, n,
+                       nblk, noise_x, noise_z);
     FGNN_HIP_CHECK(hipGetLastError());
     return FGNN_OK;
 }
@@ -354,8 +376,9 @@ extern "C" int fgnn_pauli_noise_dev(uint64_t seed, float p, const uint64_t* firs
     if (!noise_x || !noise_z || !first_sample_dev) return fgnn_fail(FGNN_ERR_ARG, "bad noise arguments");
     const int nblk = (n + 3) / 4;
     const long long total = (long long)B * nblk;
-    hipLaunchKernelGGL(pauli_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), seed,
-                       p, offset, reinterpret_cast<const unsigned long long*>(first_sample_dev), B, n, nblk, noise_x, noise_z);
+    hipLaunchKernelGGL(pauli_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), seed,
+                       p, fg_pauli_thr{0.0f, 0.0f, 0.0f}, offset, reinterpret_cast<const unsigned long long*>(first_sample_dev), B, n,
+                       nblk, noise_x, noise_z);
     FGNN_HIP_CHECK(hipGetLastError());
     return FGNN_OK;
 }

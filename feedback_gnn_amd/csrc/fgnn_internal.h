@@ -42,9 +42,9 @@ struct fgnn_graph {
     bool shortcut = true;        // exact wave-uniform shortcuts for saturated nodes (fgnn_graph_set_option)
     bool early_exit = true;      // exact fixed-point exit of the iteration loop (needs shortcut; fgnn_graph_set_option)
     bool hw_transcendentals = false;  // opt-in: phi-rule BP4 on v_exp_f32 / v_log_f32, fixed dataflow, NOT bit-exact (fgnn_graph_set_option 3)
-    bool bp4_shared_lse = true;  // qubit update: the (a - b) part of the log-sum-exp once per qubit and side (fgnn_graph_set_option 5, default)
+    bool bp4_shared_lse = false; // opt-in (fgnn_graph_set_option 5): qubit update with the (a - b) part of the log-sum-exp once per qubit and side; default = one per edge, decoding_q.py:254-273 term by term
     int gnn_stream = 1;          // factored feedback GNN of a regular graph on the streaming VALU kernel (fgnn_graph_set_option 6): 0 never (MFMA tiles), 1 where it is the faster one, 2 always
-    bool gnn_factored = true;    // feedback GNN in the factored association (fgnn_graph_set_option 4, default): same function, 2/3 of the 40->20 layer gone
+    bool gnn_factored = false;   // opt-in (fgnn_graph_set_option 4): feedback GNN in the factored association (same function, 2/3 of the 40->20 layer gone); default = one Dense per edge, feedback_gnn.py:175-184 term by term
     bool force_generic = false;  // testing: run the runtime-degree kernel even on a regular graph
     std::vector<void*> allocs;
     // host copies of the canonical edge lists (fgnn_graph_edges)
@@ -78,6 +78,7 @@ struct WeightsDev {
     const float* bout;    // [4]
     const float* lane_tab;  // [132][64] per-lane MFMA operand / bias tables (fgnn_gnn.hip, mfma path)
     const float* msg_rows[2];  // [40][32] per hidden unit: W1[0..3][j], b1[j], 0,0,0, W2[j][0..19], 0 x 4 (gnn_stream_kernel)
+    const float* msg_pairs[2]; // [20][16] per two hidden units j, j+1: W1[k][j], W1[k][j+1] for k = 0..3, b1[j], b1[j+1], 0 x 6 (literal association)
     const float* emb_rows;     // [40][48] per hidden unit: We[0..42][j], be[j], Wout[j][0..2], 0
     const float* emb_quads;    // [10][192] per four hidden units j0..j0+3: We[k][j0..j0+3] for k = 0..42, be[j0..j0+3], Wout[j0+u][0..2] for u = 0..3, 0 x 4
 };

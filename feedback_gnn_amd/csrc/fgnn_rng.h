@@ -5,7 +5,7 @@
  * defines the stream instead: Philox4x32-10 (Salmon et al., SC'11; same generator family as
  * tf.random's stateless ops), key = 64-bit seed, counter = (global sample index, word block), so
  * the noise of sample i is the same on the CPU oracle, on one GPU and on any shard of 8 GPUs.
- * Integer arithmetic only; shared by the HIP kernels and the oracle.
+ * Integer arithmetic only (plus the float32 thresholds of the channel); shared by the HIP kernels and the oracle.
  */
 #ifndef FGNN_RNG_H
 #define FGNN_RNG_H
@@ -66,19 +66,24 @@ FG_FN int fg_fy_pick(float u, int remaining)
     return j < remaining - 1 ? j : remaining - 1;
 }
 
-/* Pauli.call thresholds (pauli.py:100-108) for px = pz = 2p/3, py = p/3 (feedback_gnn.py:298),
- * evaluated in float32 like the reference's tf.float32 graph:
- *   noise_x = u < px ;  noise_z = (u >= px - py) & (u < (px + pz) - py). */
+/* Pauli.call thresholds (pauli.py:100-108) for any triple (px, py, pz), evaluated in float32 like the reference's tf.float32 graph:
+ *   noise_x = u < px ;  noise_z = (u >= px - py) & (u < (px + pz) - py),
+ * i.e. u in [0, px - py): X, [px - py, px): Y, [px, px + pz - py): Z.  Additions and subtractions only: the same bits on any IEEE host
+ * or device.  fg_pauli_thresholds(p) is the depolarizing split px = pz = 2p/3, py = p/3 of every caller in the reference
+ * (feedback_gnn.py:298, bp_osd.py:107). */
 typedef struct { float px, lo, hi; } fg_pauli_thr;
 
-FG_FN fg_pauli_thr fg_pauli_thresholds(float p)
+FG_FN fg_pauli_thr fg_pauli_thresholds_xyz(float px, float py, float pz)
 {
     fg_pauli_thr t;
-    float px = (2.0f * p) / 3.0f, py = p / 3.0f, pz = (2.0f * p) / 3.0f;
     t.px = px;
     t.lo = px - py;
     t.hi = (px + pz) - py;
     return t;
+}
+FG_FN fg_pauli_thr fg_pauli_thresholds(float p)
+{
+    return fg_pauli_thresholds_xyz((2.0f * p) / 3.0f, p / 3.0f, (2.0f * p) / 3.0f);
 }
 FG_FN uint8_t fg_pauli_x(float u, fg_pauli_thr t) { return (uint8_t)(u < t.px); }
 FG_FN uint8_t fg_pauli_z(float u, fg_pauli_thr t) { return (uint8_t)((u >= t.lo) && (u < t.hi)); }

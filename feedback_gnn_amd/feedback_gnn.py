@@ -140,23 +140,38 @@ class Pauli:
 
     The reference's call (pauli.py:72-117) is accepted too: ``Pauli(wt=False)([cx, cz, px, py, pz])`` or, with ``wt=True``,
     ``([cx, cz, wt])`` — ``cx`` gives the shape ``[bs, n]`` — returning bool tensors ``(noise_x, noise_z)`` when ``cz`` is None and
-    ``(y_x, y_z, noise_x, noise_z)`` otherwise.  Only the depolarizing split every caller of the reference uses is implemented,
-    ``px = pz = 2p/3, py = p/3`` (feedback_gnn.py:298, bp_osd.py:107): other triples raise NotImplementedError.  Successive
-    reference-style calls draw successive samples of the stream."""
+    ``(y_x, y_z, noise_x, noise_z)`` otherwise.  Any triple ``(px, py, pz)`` is taken as the reference takes it (pauli.py:98-108:
+    ``noise_x = u < px``, ``noise_z = (u >= px - py) & (u < px + pz - py)`` in float32, nothing validated); the depolarizing split
+    of every caller in the reference is ``px = pz = 2p/3, py = p/3`` (feedback_gnn.py:298, bp_osd.py:107).  Successive
+    reference-style calls draw successive samples of the stream.
 
-    def __init__(self, graph=None, seed=0x5EED, wt=False, dtype=None, device=None, **kwargs):
+    SEEDING.  The reference draws from TensorFlow's global generator and never repeats; here the stream is a pure function of
+    ``(seed, sample index)``.  A channel built WITHOUT an explicit ``seed=`` takes ``0x5EED + k`` where k counts the seed-less
+    channels constructed in this process, so two channels side by side (or one built inside a loop) do not replay each other's
+    samples; pass ``seed=`` for a reproducible stream."""
+
+    _unseeded = 0  # seed-less instances constructed so far in this process
+
+    def __init__(self, graph=None, seed=None, wt=False, dtype=None, device=None, **kwargs):
         if isinstance(graph, bool):  # Pauli(True) would be dtype in the reference; be lenient with a positional wt
             graph, wt = None, graph
         self.graph = graph
+        if seed is None:
+            seed = 0x5EED + Pauli._unseeded
+            Pauli._unseeded += 1
         self.seed = int(seed)
         self.wt = bool(wt)
         self._device = device
         self._next = 0  # sample-stream position of the reference-style calls
 
     def _noise(self, B, n, p, first_sample, out, device):
+        """``p``: error rate (depolarizing split), a triple (px, py, pz), or with wt=True the weight."""
+        triple = isinstance(p, (tuple, list))
         if self.graph is not None:
             if self.wt:
                 return self.graph.pauli_noise_wt(self.seed, int(p), first_sample, int(B), out=out)
+            if triple:
+                return self.graph.pauli_noise_xyz(self.seed, p[0], p[1], p[2], first_sample, int(B), out=out)
             return self.graph.pauli_noise(self.seed, p, first_sample, int(B), out=out)
         # graph-less: the byte kernels need only n and a device
         from . import _lib
@@ -167,6 +182,9 @@ class Pauli:
         with torch.cuda.device(dev):
             if self.wt:
                 check(_lib.lib().fgnn_pauli_noise_wt(self.seed, int(p), int(first_sample), int(B), int(n), _ptr(ex), _ptr(ez), _stream(dev)))
+            elif triple:
+                check(_lib.lib().fgnn_pauli_noise_xyz(self.seed, float(np.float32(p[0])), float(np.float32(p[1])), float(np.float32(p[2])),
+                                                      int(first_sample), int(B), int(n), _ptr(ex), _ptr(ez), _stream(dev)))
             else:
                 check(_lib.lib().fgnn_pauli_noise(self.seed, float(np.float32(p)), int(first_sample), int(B), int(n), _ptr(ex), _ptr(ez),
                                                   _stream(dev)))
@@ -190,8 +208,11 @@ class Pauli:
             cx, cz, px, py, pz = inputs
             px, py, pz = float(px), float(py), float(pz)
             level = 3.0 * py
+            # the depolarizing split px = pz = 2p/3, py = p/3 of the reference's own callers (feedback_gnn.py:298: formed from a float32
+            # p inside the graph) takes the one-parameter entry point, whose thresholds are formed from p in float32 the same way —
+            # the stream of the native call; any other triple goes through as given (pauli.py:98-108)
             if abs(px - 2.0 * level / 3.0) > 1e-6 * max(level, 1e-30) or abs(pz - px) > 1e-6 * max(level, 1e-30):
-                raise NotImplementedError("Pauli: only the depolarizing split px = pz = 2p/3, py = p/3 is implemented")
+                level = (px, py, pz)
         cx_t = torch.as_tensor(cx)
         if cx_t.dim() != 2:
             raise ValueError("cx must have shape [batch_size, n]")
@@ -264,6 +285,12 @@ class Sandwich_BP_GNN_Evaluation_Model:
         first = self._next_sample + self.rank * batch_size
         self._next_sample += self.world_size * batch_size
         return first
+
+    def next_sample_range(self, batch_size):
+        """``(first, last)``: the half-open range of global Philox sample indices this rank's NEXT batch of ``batch_size`` will draw
+        (rank r of a world of W takes block r of every W consecutive blocks) — without advancing the stream."""
+        first = self._next_sample + self.rank * int(batch_size)
+        return first, first + int(batch_size)
 
     def decode(self, batch_size, p, first_sample=None, noise=None, _slot=None):
         """Noise -> syndromes -> sandwich.  Returns dict(noise_x, noise_z, x_hat, z_hat).  ``noise=(noise_x, noise_z)``: decode
@@ -342,7 +369,9 @@ class Sandwich_BP_GNN_Evaluation_Model:
         captured noise launch reads (fgnn_pauli_noise_dev) and the graph's last node advances; the host's own position is advanced
         by `replay()`, so `mc_step` / `decode` calls in between continue where the graph left off.  ``counts`` (device int64[3]) is
         the persistent accumulator the captured counting kernels add to.  For batches so small that a step is launch-bound
-        (BASELINE configs[0]: 256 codewords, five launches of 5-110 us); needs ``compact=False`` and ``streams=1``."""
+        (BASELINE configs[0]: 256 codewords, five launches of 5-110 us); needs ``compact=False`` and ``streams=1``.  The graph owns its
+        workspace and holds the weight objects it captured (``replay.workspace`` / ``replay.weights``): later calls on the model with
+        larger batches cannot pull memory from under it; weights loaded into a feedback AFTER the capture are not seen by the graph."""
         if self.compact or self.streams > 1 or self.channel.wt:
             raise ValueError("mc_graph captures the fixed i.i.d. dataflow: compact=False, streams=1, wt=False")
         B, steps, g = int(batch_size), int(steps), self.graph
@@ -357,16 +386,17 @@ class Sandwich_BP_GNN_Evaluation_Model:
         weights = [f.device_weights for f in self.feedbacks[:L - 1]]
         factors = [d.normalization_factor for d in self.decoders[:L]]
         cn_types = [d.cn_type for d in self.decoders[:L]]
-        if self._ws_batches[0] < B:
-            self._workspaces[0] = g.sandwich_workspace(B)
-            self._ws_batches[0] = B
+        # The graph bakes raw device pointers in: it gets a workspace of its OWN (the model's is re-bound whenever a later decode / mc_step /
+        # mc_steps asks for a larger batch, and the old tensor would go back to the caching allocator while every replay still writes
+        # to it), and the closure below keeps that workspace and the weight objects alive for as long as the replay callable lives
+        ws = g.sandwich_workspace(B)
 
         def body(acc):
             for j in range(steps):
                 ex, ez = g.pauli_noise(self.channel.seed, p, j * span + self.rank * B, B, first_dev=ctr)
                 sx, sz = g.syndrome(ex, ez)
                 o = g.sandwich_decode(sx, sz, iters, weights, self._llr_const(p), factors=factors, cn_types=cn_types, compact=False,
-                                      workspace=self._workspaces[0])
+                                      workspace=ws)
                 _, _, flags = g.residual(ex, ez, o["x_hat"], o["z_hat"], want_arrays=False)
                 g.count_flags(flags, acc)
 
@@ -393,6 +423,9 @@ class Sandwich_BP_GNN_Evaluation_Model:
             expected[0] = self._next_sample
 
         replay.graph, replay.steps, replay.counter = graph, steps, ctr
+        # what the captured kernels point at (advisor, round 5): pinned on the callable.  The feedbacks' weight handles are fixed at capture
+        # time — `load_weights` / `set_weights` on a Feedback_GNN afterwards uploads NEW device arrays that this graph does not see
+        replay.workspace, replay.weights, replay.counts = ws, weights, counts
         return replay
 
     def join(self):

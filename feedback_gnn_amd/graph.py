@@ -120,9 +120,9 @@ class TannerGraph:
         check(L.fgnn_graph_create(self.n, self.m_x, self.m_z, self.E_x, _np_ptr(rx), _np_ptr(cx), self.E_z, _np_ptr(rz),
                                   _np_ptr(cz), self.device.index, C.byref(h)))
         self.handle = h
-        self.gnn_factored = True  # the library default (FGNN_OPT_GNN_FACTORED)
+        self.gnn_factored = False  # the library default: the reference's association, one Dense per edge (FGNN_OPT_GNN_FACTORED is opt-in)
         self.gnn_stream = True  # the library default (FGNN_OPT_GNN_STREAM)
-        self.bp4_shared_lse = True  # the library default (FGNN_OPT_BP4_SHARED_LSE)
+        self.bp4_shared_lse = False  # the library default: one log-sum-exp per edge (FGNN_OPT_BP4_SHARED_LSE is opt-in)
         self.stage_one = bool(stage_one)
         xp, zp = (hz, hx) if stage_one else (np.asarray(code.hx_perp), np.asarray(code.hz_perp))
         self.rows_xp, self.rows_zp = int(xp.shape[0]), int(zp.shape[0])
@@ -165,8 +165,9 @@ class TannerGraph:
         check(_lib.lib().fgnn_graph_set_option(self.handle, 3, int(bool(on))))
 
     def set_gnn_factored(self, on=True):
-        """Feedback GNN in the factored association (FGNN_OPT_GNN_FACTORED): the X/Y/Z part of the first Dense once per qubit and
-        side, one last Dense on the edge-summed activations.  Same function, float32 rounding differs (<= 5e-7 on the output)."""
+        """OPT-IN re-association (FGNN_OPT_GNN_FACTORED, default off = feedback_gnn.py:175-184 term by term): the X/Y/Z part of the first
+        Dense once per qubit and side, one last Dense on the edge-summed activations.  Same real-number function, float32 rounding differs
+        (<= 5e-7 on the output): statistically the same decoder, not the reference's operation sequence."""
         check(_lib.lib().fgnn_graph_set_option(self.handle, 4, int(bool(on))))
         self.gnn_factored = bool(on)
 
@@ -181,8 +182,10 @@ class TannerGraph:
         self.gnn_stream = "always" if value == 2 else bool(value)
 
     def set_bp4_shared_lse(self, on=True):
-        """Qubit update with the (a - b)-dependent part of the log-sum-exp formed once per qubit and side instead of once per edge
-        (FGNN_OPT_BP4_SHARED_LSE): same function, 4 instead of 8 exp/log pairs per qubit and iteration."""
+        """OPT-IN re-association (FGNN_OPT_BP4_SHARED_LSE, default off = decoding_q.py:254-273 term by term): the (a - b)-dependent part
+        of the qubit update's log-sum-exp formed once per qubit and side instead of once per edge — same real-number function, 4 instead
+        of 8 exp/log pairs per qubit and iteration, v->c messages move by <= 4 ulp of the totals per update: statistically the same
+        decoder, not the reference's operation sequence."""
         check(_lib.lib().fgnn_graph_set_option(self.handle, 5, int(bool(on))))
         self.bp4_shared_lse = bool(on)
 
@@ -420,6 +423,19 @@ class TannerGraph:
                                                       _ptr(ex), _ptr(ez), _stream(self.device)))
         return ex, ez
 
+    def pauli_noise_xyz(self, seed, px, py, pz, first_sample, B, out=None):
+        """Pauli.call for any triple (px, py, pz), pauli.py:98-108 (fgnn_pauli_noise_xyz): the same Philox uniforms as `pauli_noise`."""
+        if out is None:
+            ex = self._new((B, self.n), torch.uint8)
+            ez = self._new((B, self.n), torch.uint8)
+        else:
+            ex = self._chk_out(out[0], (B, self.n), torch.uint8, "noise_x")
+            ez = self._chk_out(out[1], (B, self.n), torch.uint8, "noise_z")
+        with torch.cuda.device(self.device):
+            check(_lib.lib().fgnn_pauli_noise_xyz(int(seed), float(np.float32(px)), float(np.float32(py)), float(np.float32(pz)),
+                                                  int(first_sample), B, self.n, _ptr(ex), _ptr(ez), _stream(self.device)))
+        return ex, ez
+
     def pauli_noise_wt(self, seed, wt, first_sample, B, out=None):
         if out is None:
             ex = self._new((B, self.n), torch.uint8)
@@ -546,9 +562,9 @@ class TannerGraph:
         return out
 
     def forms_agreement(self, synd_x, synd_z, iters, weights_list, llr_const, chunk=16384, factors=None, cn_types=None):
-        """The sandwich on the same syndromes under the library's default operation sequence and under the reference's formulas
-        term by term (options 4 and 5 = 0: one Dense per edge, feedback_gnn.py:175-184; one log-sum-exp per edge,
-        decoding_q.py:254-273), compared per sample: how many samples end on different decisions, how far the marginals of the
+        """The sandwich on the same syndromes under the two OPT-IN re-associations (options 4 and 5 = 1) and under the library's default,
+        the reference's formulas term by term (options 4 and 5 = 0: one Dense per edge, feedback_gnn.py:175-184; one log-sum-exp per
+        edge, decoding_q.py:254-273), compared per sample: how many samples end on different decisions, how far the marginals of the
         last decoder (and of the first decoder alone) are apart — over all samples and over the samples both forms solve (a sample
         BP does not converge on is chaotic under ANY change of float32 rounding).  Both runs are this library's
         kernels, each bit-equal to the oracle's restatement of its form; the settings in force are restored."""
@@ -557,16 +573,16 @@ class TannerGraph:
         cn_types = ["boxplus-phi"] * len(iters) if cn_types is None else list(cn_types)
         prev = (self.gnn_factored, self.bp4_shared_lse)
         res = dict(samples=B, decisions_differ=0, max_abs_dllr=0.0, samples_gt_1e_4=0, max_abs_dllr_solved=0.0,
-                   samples_gt_1e_4_solved=0, flagged_default=0, flagged_literal=0, flagged_in_one_form_only=0,
+                   samples_gt_1e_4_solved=0, flagged_reassociated=0, flagged_literal=0, flagged_in_one_form_only=0,
                    first_decoder=dict(decisions_differ=0, max_abs_dllr=0.0, samples_gt_1e_4=0))
         try:
             for s in range(0, B, chunk):
                 sx, sz = synd_x[s:s + chunk].contiguous(), synd_z[s:s + chunk].contiguous()
                 ones = torch.ones(sx.shape[0], dtype=torch.uint8, device=self.device)
                 outs = []
-                for default in (True, False):
-                    self.set_gnn_factored(prev[0] if default else False)
-                    self.set_bp4_shared_lse(prev[1] if default else False)
+                for reassociated in (True, False):
+                    self.set_gnn_factored(reassociated)
+                    self.set_bp4_shared_lse(reassociated)
                     o = self.sandwich_decode(sx, sz, iters, weights_list, llr_const, factors=factors, cn_types=cn_types, return_llr=True)
                     o["flag"] = self.flag_update(o["x_hat"], o["z_hat"], sx, sz, ones.clone()) != 0
                     o["first"] = self.bp4_decode(sx, sz, iters[0], cn_types[0], factors[0], llr_const=llr_const, want_logits=False)
@@ -581,7 +597,7 @@ class TannerGraph:
                 if bool(solved.any()):
                     res["max_abs_dllr_solved"] = max(res["max_abs_dllr_solved"], float(d[solved].max()))
                 res["samples_gt_1e_4_solved"] += int((d[solved] > 1e-4).sum())
-                res["flagged_default"] += int(a["flag"].sum())
+                res["flagged_reassociated"] += int(a["flag"].sum())
                 res["flagged_literal"] += int(b["flag"].sum())
                 res["flagged_in_one_form_only"] += int((a["flag"] ^ b["flag"]).sum())
                 fa, fb, f = a["first"], b["first"], res["first_decoder"]

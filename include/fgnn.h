@@ -82,41 +82,37 @@ int fgnn_graph_set_launch(fgnn_graph* g, int threads_per_codeword, int codewords
  * 0 and 16.635532, the values the reference's saturation known answer fixes), ~1 ulp per elementary function, but bits that no
  * CPU oracle reproduces: on non-converged samples decisions may differ from the default path's (chaotic
  * transients).  bench.py reports its rate and its measured agreement with the exact kernel under `extras`.
- * FGNN_OPT_GNN_FACTORED (default 1; 0 = the literal term-by-term association): the feedback GNN's message MLP and mean (feedback_gnn.py:175-184) in the factored association:
+ * FGNN_OPT_GNN_FACTORED and FGNN_OPT_BP4_SHARED_LSE (both default 0 since round 6; OPT-IN re-associations of the reference's own formulas, same
+ * real-number functions, NOT the reference's float32 operation sequence).  The library's default evaluates the reference's formulas term
+ * by term — one 40 -> 20 Dense per edge (feedback_gnn.py:175-184), one reduce_logsumexp per edge (decoding_q.py:254-273) — and that is what
+ * bench.py's `value`, smoke() and every default parity test run.
+ * FGNN_OPT_GNN_FACTORED = 1: the feedback GNN's message MLP and mean (feedback_gnn.py:175-184) in the factored association:
  * [g, X, Y, Z] W1 + b1 = g W1[0,:] + ([X, Y, Z] W1[1:4,:] + b1) with the bracket formed once per qubit and side, and
- * mean_e(h_e W2 + b2) = (sum_e h_e) W2 / deg + b2 with ONE 40 -> 20 Dense per qubit and side instead of one per edge.  The same
- * real-number function (TensorFlow leaves the association of matmul / bias_add / reduce_mean to its backend, and XLA may apply
- * exactly these rewrites); float32 results differ from the literal association's by rounding only (measured <= 5e-7 on GNN
- * outputs of magnitude 0.2 .. 2.7; the 77 published rows of the nine sandwich curves, 1.2e9 codewords, land on the same z-scores:
- * max |z| 1.899 both ways, profiles/r3c_published_curves_gnn_factored.json).  The oracle restates both orders (og_graph_set_gnn_order) and the kernels equal it bit for
- * bit in either.  Applies to the kernels of the shipped architecture (fgnn_weights_create); the runtime-shaped kernel
- * (fgnn_weights_create_general, any reduce_op) always runs the literal order.
- * FGNN_OPT_BP4_SHARED_LSE (default 1; 0 = one log-sum-exp per edge, term by term): the variable-node update (decoding_q.py:254-273) evaluates, on every hx edge e of a qubit,
+ * mean_e(h_e W2 + b2) = (sum_e h_e) W2 / deg + b2 with ONE 40 -> 20 Dense per qubit and side instead of one per edge.  float32 results
+ * differ from the literal association's by rounding only (measured <= 5e-7 on GNN outputs of magnitude 0.2 .. 2.7).  Applies to the kernels
+ * of the shipped architecture (fgnn_weights_create); the runtime-shaped kernel (fgnn_weights_create_general, any reduce_op) always runs the
+ * literal order.
+ * FGNN_OPT_BP4_SHARED_LSE = 1: the variable-node update (decoding_q.py:254-273) evaluates, on every hx edge e of a qubit,
  * reduce_logsumexp([-(Z - mu_e), -(Y - mu_e)]) = max(.,.) + log(1 + exp(-|(Z - mu_e) - (Y - mu_e)|)), and the last term's argument is
  * Z - Y for all of the qubit's edges: with the option on it is formed once per qubit and side from the unshifted totals (the per-edge
- * max term stays as it is) — 4 instead of 8 exp/log pairs per qubit and iteration.  Same real-number function, NOT the same float32
- * operation sequence: a v->c message moves by the rounding of two subtractions, and BP's transient amplifies that like any other float32
- * rounding.  What a caller who diffs results against the literal form (option = 0) sees, measured per sample through the
- * whole sandwich on 65 536 samples per point, options 4 and 5 both on vs both off (profiles/r4_forms_agreement.json,
- * tests/test_gpu_literal_forms.py; bench.py prints the same comparison for its timed batch as `forms_agreement`):
- *     [[882,24]] (64, G, 16)   p <= 0.02: 0 samples with a different final decision; p <= 0.01: marginals within 7.6e-6 on every
- *                              sample the decoder solves (the one sample of 65 536 it leaves flagged at p = 0.01, under both forms,
- *                              differs by 8e-4); p = 0.02: 9 samples beyond 1e-4 (up to 0.3), 5 of them solved ones;
- *                              p = 0.03: 2 samples (0.003 %);  0.04: 18 (0.03 %);  0.05: 74 (0.11 %);  0.06: 344 (0.5 %);
- *                              0.08: 2 746 (4.2 %);  0.10: 9 611 (14.7 %) end on a different — equally valid or equally failed — estimate;
- *     [[1270,28]] (64, G, 64)  p <= 0.02: 0;  0.03: 4;  0.04: 30;  0.05: 126 (0.2 %);  0.06: 426 (0.65 %);  0.08: 4 539 (6.9 %);
- *                              0.10: 15 177 (23 %).
- * At scale (8 388 608 samples per point, profiles/r4_forms_agreement_8M.json): p = 0.01: 3 ([[882,24]]) / 6 ([[1270,28]]) samples with
- * a different final decision (4e-7 / 7e-7 of the samples: the rare ones BP-64 takes long on), 40 / 4 solved samples beyond 1e-4;
- * p = 0.02: 40 / 76 (5e-6 / 9e-6).
- * So at the benchmark's operating point p = 0.01 the default is the literal decoder sample by sample within the north-star tolerance
- * (decisions identical, LLRs within 1e-4) on all but a few samples in ten million — none in a batch of 65 536 —, at p = 0.02 on all but
- * ~1e-5 of them; in the waterfall it is the same decoder only STATISTICALLY: BP4-64
- * decodes the same number of samples (24 M compared at p = 0.06 .. 0.10 on both codes: differences within 1.8 sigma, both signs,
- * profiles/r3j_bp4_shared_lse_ab.txt), paired block-error counts on 40 M samples agree (profiles/r3v_bp4_lse_forms_mcnemar.json) and the
- * 77 published rows land on the same z-scores (max |z| 1.89, profiles/r3k_published_curves_bp4_shared_lse.json).  A caller who needs the
- * reference's operation sequence term by term sets options 4 and 5 to 0 (bench.py: `literal_forms`, 0.85 of the default's rate).  The
- * oracle restates both forms (og_graph_set_vn_shared_lse); the kernels equal it bit for bit in either.
+ * max term stays as it is) — 4 instead of 8 exp/log pairs per qubit and iteration.  A v->c message moves by the rounding of two
+ * subtractions, and BP's transient amplifies that like any other float32 rounding.
+ * What a caller who turns both on gets, against the default, per sample through the whole sandwich (these are MEASURED RATES, not
+ * guarantees; bench.py prints the same comparison for its timed batch under extras.reassociated_forms.forms_agreement):
+ *     north-star bar = decisions identical and LLRs within 1e-4.  [[882,24]] (64, G, 16), p = 0.01, 65 536 samples per window: 0 samples
+ *     with a different decision in most windows, but NOT in all: the driver's round-5 batch (global samples 327 680 - 393 215) has one
+ *     SOLVED sample at 1.03e-4, and 8.4 M samples hold 3 differing decisions and 40 solved samples beyond 1e-4 (up to 101)
+ *     (profiles/r4_forms_agreement_8M.json); p = 0.02: 40 / 8.4 M decisions differ; p = 0.03: 2 of 65 536; 0.05: 74 (0.11 %); 0.06: 344;
+ *     0.08: 2 746 (4.2 %); 0.10: 9 611 (14.7 %) end on a different — equally valid or equally failed — estimate.
+ *     [[1270,28]] (64, G, 64): p = 0.01: 6 / 8.4 M; 0.03: 4 of 65 536; 0.05: 126; 0.06: 426; 0.08: 4 539; 0.10: 15 177 (23 %).
+ *     BASELINE configs[0] as the reference constructs it ('boxplus', 0.625, p = 0.05, 256 samples): 0 decisions differ but 250 of the 256
+ *     solved samples are beyond 1e-4 (max 0.575): the 'boxplus' rule does not saturate its messages, so rounding differences persist.
+ *     Published workloads (batch 5 000 / 50 000): n1270_3r (p = 0.07) 144 of 5 000 decisions differ; osd_bp4_minsum (p = 0.09) 1 497 of 50 000.
+ * So the re-associated forms are the reference's decoder only STATISTICALLY: BP4-64 decodes the same number of samples (24 M compared
+ * at p = 0.06 .. 0.10 on both codes: differences within 1.8 sigma, both signs, profiles/r3j_bp4_shared_lse_ab.txt), paired block-error
+ * counts on 40 M samples agree (profiles/r3v_bp4_lse_forms_mcnemar.json) and the 77 published rows of the nine sandwich curves land on
+ * the same z-scores (max |z| 1.89, profiles/r3k_published_curves_bp4_shared_lse.json).  They buy ~1.15x on the sandwich step.  The oracle
+ * restates both forms (og_graph_set_gnn_order, og_graph_set_vn_shared_lse); the kernels equal it bit for bit in either.
  * FGNN_OPT_GNN_STREAM (default 1): which kernel runs the feedback GNN (either association) on a graph with 3, 4 or 5 checks per qubit and
  * side — the streaming VALU kernel (one lane per qubit, weights as scalar operands; the literal association's 40 -> 20 Dense per edge as
  * v_pk_fma_f32 on scalar weight pairs) or the MFMA-tile kernel ((3,3) only; other degrees: the runtime-degree kernel).  0: never the
@@ -204,7 +200,13 @@ int fgnn_feedback_gnn(const fgnn_graph* g, const fgnn_weights* w, const float* l
  * (feedback_gnn.py:298): Philox4x32-10 stream keyed by (seed, first_sample + b). */
 int fgnn_pauli_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, uint8_t* noise_x, uint8_t* noise_z,
                      void* stream);
-/* The same with the stream position read on the DEVICE: sample b is keyed by (*first_sample_dev + offset + b).  For Monte-Carlo loops
+/* Pauli.call (non-wt branch) for ANY triple, sionna/channel/pauli.py:98-108: noise_x = u < px, noise_z = (u >= px - py) & (u < (px + pz) - py)
+ * in float32, u the same Philox uniform as fgnn_pauli_noise (which is this call with px = pz = 2p/3, py = p/3 formed in float32).  Like
+ * the reference it validates nothing but NaNs: X, Y, Z are disjoint events of probability px - py, py, pz - py when
+ * 0 <= py <= min(px, pz) and px + pz - py <= 1. */
+int fgnn_pauli_noise_xyz(uint64_t seed, float px, float py, float pz, uint64_t first_sample, int B, int n, uint8_t* noise_x,
+                         uint8_t* noise_z, void* stream);
+/* fgnn_pauli_noise with the stream position read on the DEVICE: sample b is keyed by (*first_sample_dev + offset + b).  For Monte-Carlo loops
  * captured in a hipGraph (the reference's `while` loop of misc.py:636-738 with no host in it): the graph owns an 8-byte device counter,
  * every noise launch of the captured loop reads it, and the graph's last node advances it, so each replay draws the next samples. */
 int fgnn_pauli_noise_dev(uint64_t seed, float p, const uint64_t* first_sample_dev, uint64_t offset, int B, int n, uint8_t* noise_x,

@@ -651,9 +651,8 @@ int og_feedback_gnn_general(const og_graph* g, int D, int H, int L, int reduce_o
  * tf.random.uniform is unseeded in the reference; the build defines the stream:
  * Philox4x32-10, key = seed, counter = (sample index, word block) — see fgnn_rng.h.
  * ------------------------------------------------------------------------------------------ */
-int og_pauli_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, uint8_t* noise_x, uint8_t* noise_z)
+static int og_pauli_noise_thr(uint64_t seed, fg_pauli_thr thr, uint64_t first_sample, int B, int n, uint8_t* noise_x, uint8_t* noise_z)
 {
-    fg_pauli_thr thr = fg_pauli_thresholds(p);
 #pragma omp parallel for schedule(static)
     for (int b = 0; b < B; ++b)
         for (int q0 = 0; q0 < n; q0 += 4) {
@@ -665,6 +664,19 @@ int og_pauli_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, 
             }
         }
     return 0;
+}
+
+int og_pauli_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, uint8_t* noise_x, uint8_t* noise_z)
+{
+    return og_pauli_noise_thr(seed, fg_pauli_thresholds(p), first_sample, B, n, noise_x, noise_z);
+}
+
+/* Pauli.call for any triple (px, py, pz), pauli.py:98-108 term by term: noise_x = u < px (:103), mask1 = u >= px - py (:104),
+ * mask2 = u < (px + pz) - py (:105), noise_z = mask1 & mask2 (:106), all in float32. */
+int og_pauli_noise_xyz(uint64_t seed, float px, float py, float pz, uint64_t first_sample, int B, int n, uint8_t* noise_x,
+                       uint8_t* noise_z)
+{
+    return og_pauli_noise_thr(seed, fg_pauli_thresholds_xyz(px, py, pz), first_sample, B, n, noise_x, noise_z);
 }
 
 /* Pauli.call with wt=True (pauli.py:80-97): exactly `wt` qubits carry an error, X/Y/Z equiprobable. */

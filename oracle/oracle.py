@@ -46,6 +46,7 @@ def lib():
         _lib.og_feedback_gnn.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_void_p]
         _lib.og_feedback_gnn_general.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
         _lib.og_pauli_noise.argtypes = [C.c_uint64, C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.og_pauli_noise_xyz.argtypes = [C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib.og_syndrome.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib.og_residual.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3
         _lib.og_sandwich_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -142,13 +143,14 @@ class OracleGraph:
     (decoding_q.py:35-37); otherwise code.hx_perp / code.hz_perp.
     """
 
-    FORMS = ("library-default", "literal")
+    FORMS = ("library-default", "literal", "reassociated")
 
     def __init__(self, code, stage_one=True, *, forms):
         """``forms`` (required, so that every caller says which restatement it checks against): "literal" = the reference's formulas
         term by term (one log-sum-exp per edge, decoding_q.py:254-273; one Dense per edge, feedback_gnn.py:175-184, gnn.py:573-610);
-        "library-default" = the two re-associations libfgnn_hip runs by default (FGNN_OPT_BP4_SHARED_LSE, FGNN_OPT_GNN_FACTORED).
-        Both are restated in fgnn_oracle.c; set_gnn_order / set_vn_shared_lse switch them one by one afterwards."""
+        "library-default" = what libfgnn_hip runs out of the box — since round 6 that IS the literal restatement; "reassociated" = the
+        library's two opt-in re-associations (FGNN_OPT_BP4_SHARED_LSE, FGNN_OPT_GNN_FACTORED).  All are restated in fgnn_oracle.c;
+        set_gnn_order / set_vn_shared_lse switch them one by one afterwards."""
         if forms not in self.FORMS:
             raise ValueError(f"forms must be one of {self.FORMS}")
         L = lib()
@@ -160,8 +162,8 @@ class OracleGraph:
         self.E_x, self.E_z = len(rx), len(rz)
         self.h = L.og_graph_create(self.n, self.m_x, self.m_z, self.E_x, _p(rx), _p(cx), self.E_z, _p(rz), _p(cz))
         self.forms = forms
-        self.set_gnn_order(forms == "library-default")
-        self.set_vn_shared_lse(forms == "library-default")
+        self.set_gnn_order(forms == "reassociated")
+        self.set_vn_shared_lse(forms == "reassociated")
         xp, zp = (code.hz, code.hx) if stage_one else (code.hx_perp, code.hz_perp)
         self.rows_xp, self.rows_zp = int(xp.shape[0]), int(zp.shape[0])
         self.rows_lx, self.rows_lz = int(np.asarray(code.lx).shape[0]), int(np.asarray(code.lz).shape[0])
@@ -255,6 +257,14 @@ class OracleGraph:
         ex = np.empty((B, self.n), np.uint8)
         ez = np.empty((B, self.n), np.uint8)
         lib().og_pauli_noise(int(seed), float(np.float32(p)), int(first_sample), B, self.n, _p(ex), _p(ez))
+        return ex, ez
+
+    def pauli_noise_xyz(self, seed, px, py, pz, first_sample, B):
+        """Pauli.call for any triple (pauli.py:98-108)."""
+        ex = np.empty((B, self.n), np.uint8)
+        ez = np.empty((B, self.n), np.uint8)
+        lib().og_pauli_noise_xyz(int(seed), float(np.float32(px)), float(np.float32(py)), float(np.float32(pz)), int(first_sample), B,
+                                 self.n, _p(ex), _p(ez))
         return ex, ez
 
     def syndrome(self, ex, ez):

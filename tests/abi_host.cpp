@@ -25,7 +25,7 @@ og_graph* og_graph_create(int n, int m_x, int m_z, int E_x, const int32_t* chk_x
                           const int32_t* chk_z, const int32_t* var_z);
 void og_graph_set_rows(og_graph* g, int which, int rows, int nnz, const int32_t* r, const int32_t* c);
 void og_graph_set_gnn_order(og_graph* g, int factored);      // 0 (initial) = the reference's formulas term by term,
-void og_graph_set_vn_shared_lse(og_graph* g, int shared);    // 1 = the re-association libfgnn_hip runs by default
+void og_graph_set_vn_shared_lse(og_graph* g, int shared);    // 1 = the library's opt-in re-association (fgnn_graph_set_option 4 / 5)
 void og_graph_destroy(og_graph* g);
 int og_pauli_noise(uint64_t seed, float p, uint64_t first_sample, int B, int n, uint8_t* noise_x, uint8_t* noise_z);
 int og_syndrome(const og_graph* g, const uint8_t* ex, const uint8_t* ez, int B, uint8_t* synd_x, uint8_t* synd_z);
@@ -152,9 +152,10 @@ int main(int argc, char** argv)
     og_graph* og = og_graph_create(n, m, m, E, hx.r.data(), hx.c.data(), E, hz.r.data(), hz.c.data());
     og_graph_set_rows(og, 0, m, E, hz.r.data(), hz.c.data());  // stage_one: pcm_x_perp = hz, pcm_z_perp = hx (decoding_q.py:35-37)
     og_graph_set_rows(og, 1, m, E, hx.r.data(), hx.c.data());
-    // the checker restates the forms the library runs by default (FGNN_OPT_GNN_FACTORED = FGNN_OPT_BP4_SHARED_LSE = 1)
-    og_graph_set_gnn_order(og, 1);
-    og_graph_set_vn_shared_lse(og, 1);
+    // the checker restates the forms the library runs by default: the reference's formulas term by term
+    // (FGNN_OPT_GNN_FACTORED = FGNN_OPT_BP4_SHARED_LSE = 0, the oracle's initial state — set explicitly)
+    og_graph_set_gnn_order(og, 0);
+    og_graph_set_vn_shared_lse(og, 0);
     std::vector<uint8_t> ex((size_t)B * n), ez((size_t)B * n), sx((size_t)B * m), sz((size_t)B * m), oxh((size_t)B * n),
         ozh((size_t)B * n), bxh((size_t)B * n), bzh((size_t)B * n);
     std::vector<float> ollr((size_t)B * 3 * n), bllr((size_t)B * 3 * n), bxl((size_t)B * m), bzl((size_t)B * m);

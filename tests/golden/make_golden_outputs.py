@@ -14,8 +14,9 @@ Two kinds of content:
   feedback_gnn.py:321-340.  Tests hold GPU and C-oracle output to them with the north-star tolerances (same correction on the
   converged samples, LLR <= 1e-4).
 * FROZEN BITS of the C oracle (CRC-32 of its full float / byte outputs for 1, 2, 16, 64 iterations, of the GNN output, and the
-  per-sample (flagged, logical error) bytes of two sandwiches on 4 096 samples), in the library's default forms
-  (FGNN_OPT_GNN_FACTORED = 1, FGNN_OPT_BP4_SHARED_LSE = 1) and, for the BP4 and GNN outputs, in the literal forms as well.  Kernel == oracle is exact equality everywhere, so
+  per-sample (flagged, logical error) bytes of two sandwiches on 4 096 samples), in the library's default forms (since round 6 the
+  reference's formulas term by term: FGNN_OPT_GNN_FACTORED = 0, FGNN_OPT_BP4_SHARED_LSE = 0) and in the opt-in re-associated forms
+  (keys `.../reassociated/...`: the values the round-3..5 fixture held as its default).  Kernel == oracle is exact equality everywhere, so
   these pin the kernels too.  They MUST change when the shared arithmetic changes — then this script is re-run and the new file
   committed as an explicit re-pin, with the statistical re-validation DESIGN.md §3 describes.  They must NOT change otherwise.
 
@@ -82,13 +83,13 @@ def main():
         out[f"{key}/llr_converged"] = r["llr"][conv]              # [n_conv,3,n] float32, NumPy arithmetic
         out[f"{key}/x_logit_converged"] = r["x_logit"][conv]
         out[f"{key}/z_logit_converged"] = r["z_logit"][conv]
-        for lse in (0, 1):  # both forms of the qubit update's log-sum-exp (FGNN_OPT_BP4_SHARED_LSE); 1 is the default
+        for lse in (0, 1):  # both forms of the qubit update's log-sum-exp (FGNN_OPT_BP4_SHARED_LSE); 0 is the default
             og.set_vn_shared_lse(lse)
             for f in CRC_FACTORS:
                 for it in CRC_ITERS:
                     o = og.bp4_decode(sx, sz, it, "boxplus-phi", f, llr_const=L0)
                     out[f"{key}/crc_lse{lse}_f{f:.1f}_it{it}"] = bp_crc(o)
-        og.set_vn_shared_lse(1)
+        og.set_vn_shared_lse(H.LIBRARY_BP4_SHARED_LSE)
         print(key, "converged (numpy)", int(conv.sum()), "of", B, flush=True)
     np.savez_compressed(os.path.join(HERE, "bp4_full.npz"), **out)
 
@@ -114,7 +115,7 @@ def main():
             o = og.feedback_gnn(w, gin["llr"], gin["logit_hx"], gin["logit_hz"], gin["synd_x"], gin["synd_z"])
             g[f"{wfile}/crc_order{order}"] = crc(o)
             print("gnn", wfile, "order", order, "max|oracle - numpy|", float(np.abs(o - ref).max()), "range", float(ref.min()), float(ref.max()))
-        og.set_gnn_order(1)
+        og.set_gnn_order(H.LIBRARY_GNN_FACTORED)
     np.savez_compressed(os.path.join(HERE, "gnn.npz"), **g)
 
     # ---------------- sandwich.npz ----------------
@@ -139,20 +140,21 @@ def main():
     s["numpy/flagged"], s["numpy/block_error"] = flagged, logical
     s["numpy/x_hat"], s["numpy/z_hat"] = np.packbits(xh, axis=1), np.packbits(zh, axis=1)
     print("sandwich numpy: BP-64 failures", int(errors.sum()), "flagged after GNN+16", int(flagged.sum()), "block errors", int(logical.sum()))
-    # (ii) frozen bits of the C oracle: two sandwiches on 4 096 samples
+    # (ii) frozen bits of the C oracle: two sandwiches on 4 096 samples, in the library's default (literal) forms and in the opt-in
+    # re-associated forms
     for name, iters, p, B, first in SANDWICHES:
-        og = H.oracle_library_forms(name)
-        ex, ez = og.pauli_noise(SEED, p, first, B)
-        sx, sz = og.syndrome(ex, ez)
-        o = og.sandwich_decode(sx, sz, iters, [w] * (len(iters) - 1), L0, return_llr=True)
-        _, _, fl = og.residual(ex, ez, o["x_hat"], o["z_hat"])
         key = f"{name}_{'-'.join(map(str, iters))}"
-        s[f"{key}/first_sample"], s[f"{key}/p"], s[f"{key}/B"] = np.int64(first), np.float32(p), np.int64(B)
-        s[f"{key}/flags"] = fl            # bit 0 = flagged, bit 1 = block error (misc.py:649-651)
-        s[f"{key}/rounds"] = o["rounds"]
-        s[f"{key}/crc_decisions"] = crc(o["x_hat"], o["z_hat"])
-        s[f"{key}/crc_llr"] = crc(o["llr"])
-        print(key, "flagged", int((fl & 1).sum()), "block errors", int(((fl >> 1) & 1).sum()), "of", B, flush=True)
+        for sub, og in (("", H.oracle_library_forms(name)), ("reassociated/", H.oracle_reassociated_forms(name))):
+            ex, ez = og.pauli_noise(SEED, p, first, B)
+            sx, sz = og.syndrome(ex, ez)
+            o = og.sandwich_decode(sx, sz, iters, [w] * (len(iters) - 1), L0, return_llr=True)
+            _, _, fl = og.residual(ex, ez, o["x_hat"], o["z_hat"])
+            s[f"{key}/first_sample"], s[f"{key}/p"], s[f"{key}/B"] = np.int64(first), np.float32(p), np.int64(B)
+            s[f"{key}/{sub}flags"] = fl            # bit 0 = flagged, bit 1 = block error (misc.py:649-651)
+            s[f"{key}/{sub}rounds"] = o["rounds"]
+            s[f"{key}/{sub}crc_decisions"] = crc(o["x_hat"], o["z_hat"])
+            s[f"{key}/{sub}crc_llr"] = crc(o["llr"])
+            print(key, sub or "default/", "flagged", int((fl & 1).sum()), "block errors", int(((fl >> 1) & 1).sum()), "of", B, flush=True)
     np.savez_compressed(os.path.join(HERE, "sandwich.npz"), **s)
     # ---------------- other_paths.npz: frozen bits of the remaining kernels' oracle restatements ----------------
     # (the min-sum and tanh check-node rules, binary syndrome BP, OSD-0, GNN_BP4 in both associations and one runtime-shaped setting)
@@ -167,7 +169,7 @@ def main():
             og.set_vn_shared_lse(lse)
             o = og.bp4_decode(sx, sz, it, cn, fac, llr_const=L0)
             m[f"bp4_{cn}_{fac}_{it}/crc_lse{lse}"] = bp_crc(o)
-    og.set_vn_shared_lse(1)
+    og.set_vn_shared_lse(H.LIBRARY_BP4_SHARED_LSE)
     e = og.bsc_noise(SEED, 0.04, first, B)
     synd = ((e.astype(np.int64) @ np.asarray(code.hx, dtype=np.int64).T) % 2).astype(np.uint8)
     Lb = float(-np.log((np.float32(1) - np.float32(0.2)) / np.float32(0.2), dtype=np.float32))
@@ -205,7 +207,7 @@ def main():
         og.set_gnn_order(order)
         o = og.gnn_bp4(w0, sx[:6], sz[:6], 5)
         m[f"gnnbp4/crc_order{order}"] = crc(o["llr"], o["x_logit_all"], o["z_logit_all"], o["x_hat"], o["z_hat"])
-    og.set_gnn_order(1)
+    og.set_gnn_order(H.LIBRARY_GNN_FACTORED)
     o = og.gnn_bp4_general(cfg1, w1, sx[:6], sz[:6], 4)
     m["gnnbp4/crc_general"] = crc(o["llr"], o["x_logit_all"], o["z_logit_all"], o["x_hat"], o["z_hat"])
     r = NR2.gnn_bp4_general(code, cfg1, w1, sx[:6], sz[:6], 4)

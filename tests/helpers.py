@@ -68,11 +68,12 @@ def _oracle_graph(name, stage_one, forms):
 
 
 def oracle_library_forms(name, stage_one=True):
-    """The checker of the default parity tests: the oracle's restatement of the operation sequence libfgnn_hip runs BY DEFAULT
-    (FGNN_OPT_GNN_FACTORED = FGNN_OPT_BP4_SHARED_LSE = 1: Dense layers factored, the log-sum-exp term shared per qubit side) — what
-    `gpu_graph(name)` computes out of the box.  Not the reference's formulas term by term: that restatement is `oracle_literal_forms`,
-    and tests/test_gpu_literal_forms.py, test_gpu_bp4_shared_lse.py and test_gpu_gnn_order.py hold the kernels to it with the two
-    options off.  One cached graph per (code, stage_one); tests that flip a form with its setters restore it."""
+    """The checker of the default parity tests: the oracle's restatement of the operation sequence libfgnn_hip runs BY DEFAULT — what
+    `gpu_graph(name)` computes out of the box.  Since round 6 that is the reference's formulas term by term (FGNN_OPT_GNN_FACTORED =
+    FGNN_OPT_BP4_SHARED_LSE = 0: one Dense per edge, one log-sum-exp per edge), i.e. the same restatement as `oracle_literal_forms`;
+    the two opt-in re-associations are `oracle_reassociated_forms`, and tests/test_gpu_bp4_shared_lse.py, test_gpu_gnn_order.py and
+    test_gpu_literal_forms.py hold the kernels to the oracle with the options on and off.  One cached graph per (code, stage_one);
+    tests that flip a form with its setters restore it (LIBRARY_FORMS below)."""
     return _oracle_graph(name, stage_one, "library-default")
 
 
@@ -80,6 +81,17 @@ def oracle_literal_forms(name, stage_one=True):
     """The oracle's restatement of the reference's formulas term by term: one log-sum-exp per edge (decoding_q.py:254-273), one Dense per
     edge (feedback_gnn.py:175-184, gnn.py:573-610)."""
     return _oracle_graph(name, stage_one, "literal")
+
+
+def oracle_reassociated_forms(name, stage_one=True):
+    """The oracle's restatement of the library's two opt-in re-associations (Dense layers factored, the log-sum-exp term shared per qubit
+    side): the checker of a GPU graph with `set_gnn_factored(True)` and `set_bp4_shared_lse(True)`."""
+    return _oracle_graph(name, stage_one, "reassociated")
+
+
+# what a fresh TannerGraph / OracleGraph(forms="library-default") runs: tests that switch a form restore these values
+LIBRARY_GNN_FACTORED = False
+LIBRARY_BP4_SHARED_LSE = False
 
 
 @functools.lru_cache(maxsize=None)

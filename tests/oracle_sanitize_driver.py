@@ -39,7 +39,7 @@ for name in ("steane", "rsurf3", "rsurf5", "toric4", "gb48", "gb48_oc", "ghp882"
             g.set_vn_shared_lse(lse)
             o = g.bp4_decode(sx, sz, 5, cn, 0.8, llr_const=L0, return_msgs=True)
             g.bp4_decode(sx, sz, 2, cn, 1.0, llr_ch=o["llr"], msg_init=(o["msg_x"], o["msg_z"]))
-    g.set_vn_shared_lse(1)
+    g.set_vn_shared_lse(0)  # the library default
     g.residual(ex, ez, o["x_hat"], o["z_hat"])
     e = g.bsc_noise(SEED, 0.05, 0, B)
     synd = ((e.astype(np.int64) @ np.asarray(c.hx, dtype=np.int64).T) % 2).astype(np.uint8)
@@ -52,7 +52,7 @@ for name in ("steane", "rsurf3", "rsurf5", "toric4", "gb48", "gb48_oc", "ghp882"
             g.feedback_gnn(w, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
             g.sandwich_decode(sx, sz, [4, 3, 2], [w, w], L0, return_llr=True)
             g.gnn_bp4(rnd(NR.gnn_bp4_general_shapes(c, (20, 40, 2, 1, 1, 1, 0, 0, 0))), sx, sz, 2)
-        g.set_gnn_order(1)
+        g.set_gnn_order(0)  # the library default
         g.feedback_gnn_general((8, 16, 3, 2, 2, 0), rnd([(16, 3)] + [(4, 16), (16, 16), (16, 8)] * 2 + [(19, 16), (16, 16)]),
                                o["llr"], o["z_logit"], o["x_logit"], sx, sz)
         for cfg in ((12, 24, 3, 0, 3, 1, 1, 3, 2), (32, 96, 4, 2, 1, 0, 1, 16, 16), (5, 7, 1, 3, 0, 1, 0, 0, 0)):

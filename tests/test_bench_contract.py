@@ -57,12 +57,19 @@ def test_bench_prints_one_contract_line():
     assert gn["bound"] == "mfma" and gn["unit"] == "TFLOP/s" and gn["peak"] == 157.3 and gn["launches_timed"] == 2
     assert "MFMA-tile" in gn["kernel"] and gn["traffic"] is None and "no entry" in gn["traffic_source"]  # no PMC counts at this small batch
     assert abs(gn["frac"] - gn["reference_tflops_frac_of_f32_peak"]) < 1e-12 and gn["achieved"] == gn["reference_tflops"]
-    assert gn["algorithmic_flops_per_launch"] == 13406400 * 2048 and gn["executed_flops_per_launch"] == 6914880 * 2048
+    assert gn["algorithmic_flops_per_launch"] == gn["executed_flops_per_launch"] == 13406400 * 2048  # literal association: one Dense per edge
     ref_tf = gn["algorithmic_flops_per_launch"] / (gn["avg_launch_ms"] * 1e-3) / 1e12
     assert abs(gn["reference_tflops"] - ref_tf) < 1e-6 * ref_tf
-    assert abs(gn["reference_tflops_frac_of_f32_peak"] - ref_tf / 157.3) < 1e-9 and gn["executed_frac"] < gn["reference_tflops_frac_of_f32_peak"] <= 1.0
-    assert d["config"]["gnn_association"] == "factored" and d["config"]["gnn_kernel"] == "MFMA tiles"  # 2 048 < 4 096 codewords: the library's own choice
+    assert abs(gn["reference_tflops_frac_of_f32_peak"] - ref_tf / 157.3) < 1e-9 and gn["executed_frac"] <= gn["reference_tflops_frac_of_f32_peak"] <= 1.0
+    # round 6: the headline is the library default = the reference's formulas term by term
+    assert d["config"]["gnn_association"] == "literal" and d["config"]["bp4_qubit_update_lse"] == "per edge (literal)" and "term by term" in d["value_is"]
+    assert d["config"]["gnn_kernel"] == "MFMA tiles"  # 2 048 < 4 096 codewords: the library's own choice
+    assert r["mfma_insts_per_launch"] is None and r["mfma_busy_frac"] is None and "mfma_busy_frac" in gn  # no PMC entry at this batch: nulls, never a stale number
     assert d["per_rank_ms"] == [d["ms_per_step"]]
+    sh = d["dist"]["sharding"]  # one rank: its two timed batches are samples [2048, 6144)
+    assert d["dist"]["ranks"][0]["timed_samples"] == [2048, 3 * 2048] == sh["timed_region_samples"] and sh["batches"] == 2
+    assert sh["ranges_tile_the_region_without_overlap"] is True and sh["sum_of_rank_counts_equals_all_reduced"] is True
+    assert d["dist"]["ranks"][0]["own_counts"] == d["counts"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "codewords/s" and c["cores"] >= 1 and c["value"] > 0 and "256 codewords" in c["sample"]
     assert c["gpu_matches_oracle_bit_exact"] is True
@@ -70,15 +77,19 @@ def test_bench_prints_one_contract_line():
     assert t["kind"] == "port" and t["unit"] == "codewords/s" and t["cores"] >= 1 and t["value"] > 0 and "256 codewords" in t["sample"]
     assert t["decisions_identical_to_oracle_on_samples_both_decode"] >= 0.95 and t["samples_both_decode"] >= 250
     assert d["counts"]["samples"] == 2 * 2048
-    # round 4: the parity claim of the headline is checkable in the line.  literal_forms = the same step with the reference's formulas
-    # term by term, timed in the same run; forms_agreement = the first timed batch decoded under both forms, compared per sample
-    lf, fa = d["literal_forms"], d["forms_agreement"]
-    assert lf["unit"] == "codewords/s" and lf["steps"] == 2 and lf["value"] > 0
-    assert abs(lf["value"] - 2 * 2048 / (lf["ms_per_step"] * 2e-3)) < 1e-6 * lf["value"]
-    assert fa["samples"] == 2048 and fa["p"] == 0.01 and fa["decisions_differ"] == 0 and fa["max_abs_dllr_solved"] <= 1e-4
+    # literal_forms = the headline itself (the key of earlier rounds); reassociated_forms (with --no-extras at top level, else under extras) =
+    # the same step under the two opt-in re-associations, timed in the same run, with forms_agreement = the first timed batch decoded
+    # under both forms, compared per sample (on THIS window of 2 048 samples at p = 0.01 they agree; that is a measurement, not a guarantee)
+    lf, rf = d["literal_forms"], d["reassociated_forms"]
+    assert lf["value"] == d["value"] and lf["ms_per_step"] == d["ms_per_step"] and lf["unit"] == "codewords/s" and lf["steps"] == 2
+    assert rf["unit"] == "codewords/s" and rf["steps"] == 2 and rf["value"] > 0 and "opt-in" in rf["forms"].lower()
+    assert abs(rf["value"] - 2 * 2048 / (rf["ms_per_step"] * 2e-3)) < 1e-6 * rf["value"]
+    fa = rf["forms_agreement"]
+    assert fa["samples"] == 2048 and fa["p"] == 0.01 and fa["first_sample"] == 2048 and fa["decisions_differ"] == 0 and fa["max_abs_dllr_solved"] <= 1e-4
+    assert "forms_agreement" not in d
     assert set(fa["first_decoder"]) == {"decisions_differ", "max_abs_dllr", "samples_gt_1e_4"}
     # algorithmic efficiency next to issue utilisation: every exp / log of the fixed dataflow against the hardware transcendental rate
-    assert r["transcendental_evals_per_codeword"] == {"exp": 64 * 16 * 882 + 4 * 882 + 5292 + 882, "log": 64 * 28 * 882 + 4 * 882 + 2 * (5292 + 882)}
+    assert r["transcendental_evals_per_codeword"] == {"exp": 64 * 20 * 882 + 4 * 882 + 5292 + 882, "log": 64 * 32 * 882 + 4 * 882 + 2 * (5292 + 882)}
     assert r["transcendental_evals_per_launch"] == 2048 * sum(r["transcendental_evals_per_codeword"].values())
     hw = r["transcendental_evals_per_launch"] / (r["avg_launch_ms"] * 1e-3) / r["hw_transcendental_peak_per_s"]
     assert abs(r["frac_of_hw_transcendental_rate"] - hw) < 1e-9 and r["hw_transcendental_peak_per_s"] == 1024 * 64 * 2.4e9 / 8
@@ -158,18 +169,19 @@ def test_bench_lines_of_the_other_two_configs(config, batch):
     assert r["frac"] is None and "no entry" in r["traffic_source"] and r["launches_timed"] == 2 and r["avg_launch_ms"] > 0
     assert c["kind"] == "port" and c["value"] > 0 and c["gpu_matches_oracle_bit_exact"] is True and "32 codewords" in c["sample"]
     assert d["cpu_baseline_tf_like"]["value"] > 0
-    assert d["forms_agreement"]["samples"] == batch and d["literal_forms"]["value"] > 0
+    fa = d["reassociated_forms"]["forms_agreement"]
+    assert fa["samples"] == batch and d["literal_forms"]["value"] == d["value"] and d["config"]["gnn_association"] == "literal"
     if config == "c5":
         # untrained (seeded) weights leave marginals within 1e-5 of the argmin boundary: the decisions of such qubits may flip under the
         # 1e-6 rounding difference of the two associations; none may flip beyond the LLR tolerance
-        assert d["forms_agreement"]["decisions_differ_beyond_llr_tolerance"] == 0
-        assert d["forms_agreement"]["max_decision_margin_where_they_differ"] <= 2e-4
+        assert fa["decisions_differ_beyond_llr_tolerance"] == 0
+        assert fa["max_decision_margin_where_they_differ"] <= 2e-4
         assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and d["config"]["gnn_bp4_iters"] == 10
         assert r["algorithmic_flops_per_launch"] == batch * (10 * (7620 * 2 * 2400 + 1270 * 2 * 3200) + 9 * (7620 * 2 * 2400 + 1270 * 2 * 2440))
         tf = r["algorithmic_flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12
-        assert abs(r["reference_tflops"] - tf) < 1e-6 * tf and d["forms_agreement"]["max_abs_dllr"] <= 1e-4
+        assert abs(r["reference_tflops"] - tf) < 1e-6 * tf and fa["max_abs_dllr"] <= 1e-4
     else:
-        assert d["forms_agreement"]["decisions_differ"] == 0
+        assert fa["decisions_differ"] <= 1  # a measured rate on this window of 1 024 samples at p = 0.01, not a guarantee
         assert r["bound"] == "valu" and d["config"]["bp_iters"] == [64, 64] and "configs[3]" in d["config"]["workload"]
         assert r["later_decoders_avg_launch_ms"] > 0 and r["gnn"]["launches_timed"] == 2
 
@@ -195,8 +207,9 @@ def test_bench_lines_of_the_bp4_only_configs():
         assert f"bp4_kernel<{cn}>" in r["kernel"]
         assert r["gnn"] is None and r["launches_timed"] == 4 and r["later_decoders_avg_launch_ms"] is None
         assert (r["frac"] is not None and 0 < r["frac"] <= 1) if ent else r["frac"] is None
-        assert d["cpu_baseline"]["gpu_matches_oracle_bit_exact"] is True and d["forms_agreement"]["samples"] == 256
-        assert d["forms_agreement"]["p"] == 0.05  # the agreement of the default forms with the literal ones at the configuration's own p
+        fa = d["reassociated_forms"]["forms_agreement"]
+        assert d["cpu_baseline"]["gpu_matches_oracle_bit_exact"] is True and fa["samples"] == 256
+        assert fa["p"] == 0.05  # the agreement of the opt-in forms with the default (literal) ones at the configuration's own p
         assert d["cpu_baseline_tf_like"]["value"] > 0
         assert d["counts"]["samples"] == 4 * 256 and d["literal_forms"]["value"] > 0
         assert d["dist"]["world_size"] == 1 and d["dist"]["ranks"][0]["device_index"] == 0 and "value_is" in d
@@ -206,7 +219,7 @@ def test_bench_lines_of_the_bp4_only_configs():
     assert res.returncode == 0, res.stderr[-2000:]
     d = json.loads([l for l in res.stdout.splitlines() if l.strip()][0])
     assert d["metric"] == "decoded codewords/sec, [[882,24]] BP4 64 iters" and "BP4-64 alone" in d["config"]["workload"]
-    assert d["roofline"]["gnn"] is None and d["roofline"]["frac"] is None and d["forms_agreement"]["decisions_differ"] == 0
+    assert d["roofline"]["gnn"] is None and d["roofline"]["frac"] is None and d["reassociated_forms"]["forms_agreement"]["decisions_differ"] <= 1
     assert d["cpu_baseline"]["gpu_matches_oracle_bit_exact"] is True
 
 
@@ -224,7 +237,8 @@ def test_bench_line_of_a_published_workload():
     assert d["counts"]["samples"] == 3 * 5000 and d["config"]["streams"] == 1
     t = d["two_streams"]
     assert t["streams"] == 2 and t["value"] > 0 and abs(t["value"] - 3 * 5000 / (t["ms_per_step"] * 3e-3)) < 1e-6 * t["value"]
-    assert d["literal_forms"]["value"] > 0 and d["forms_agreement"]["samples"] == 5000 and d["forms_agreement"]["p"] == 0.05
+    fa = d["reassociated_forms"]["forms_agreement"]
+    assert d["literal_forms"]["value"] == d["value"] and fa["samples"] == 5000 and fa["p"] == 0.05
     r = d["roofline"]
     assert r["launches_timed"] == 3 and r["later_decoders_avg_launch_ms"] > 0 and r["gnn"]["launches_timed"] == 9
     assert "streaming VALU" in r["gnn"]["kernel"] and d["config"]["gnn_kernel"] == "streaming VALU"  # 5 000 >= 4 096 codewords
@@ -244,7 +258,13 @@ def test_other_configs_shard_over_two_ranks(config, batch):
     assert res.returncode == 0, res.stderr[-2000:]
     d = json.loads([l for l in res.stdout.splitlines() if l.lstrip().startswith("{")][0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * batch and len(d["per_rank_ms"]) == 2
-    assert d["counts"]["samples"] == 2 * 2 * batch and "literal_forms" in d and "forms_agreement" in d
+    assert d["counts"]["samples"] == 2 * 2 * batch and d["literal_forms"]["value"] == d["value"] and "reassociated_forms" not in d
+    # the sharding proof of the multi-GPU line (round 6): rank r's timed batches are blocks r of every 2 consecutive blocks of `batch`
+    sh, rows = d["dist"]["sharding"], d["dist"]["ranks"]
+    assert [r["timed_samples"] for r in rows] == [[2 * batch, 2 * batch + 4 * batch - batch], [3 * batch, 6 * batch]]
+    assert sh["timed_region_samples"] == [2 * batch, 6 * batch] and sh["batches"] == 4 and sh["ranges_tile_the_region_without_overlap"] is True
+    assert sh["sum_of_rank_counts_equals_all_reduced"] is True and sh["sum_of_rank_counts"] == d["counts"]
+    assert sum(r["own_counts"]["samples"] for r in rows) == 4 * batch and all(r["own_counts"]["samples"] == 2 * batch for r in rows)
     res1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(2 * batch), "--no-build"] + common,
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
     assert res1.returncode == 0, res1.stderr[-2000:]
@@ -335,6 +355,13 @@ def test_bench_three_ranks_equal_one_process_over_the_same_global_samples():
     assert [r["local_rank"] for r in ds["ranks"]] == [0, 1, 2] and {r["device_index"] for r in ds["ranks"]} == {0}
     assert len({r["pid"] for r in ds["ranks"]}) == N and all("MI3" in r["device_name"] or r["device_name"] for r in ds["ranks"])
     assert ds["one_distinct_device_per_rank"] is False
+    # every rank's global sample range of the timed region and its own counters; rank 0 has checked that the per-step ranges tile
+    # [W * world * B, (W + K) * world * B) without overlap and that the ranks' counters add up to the all-reduced ones (else: exit 8)
+    assert [r["timed_samples"] for r in ds["ranks"]] == [[(N + k) * Bq, (2 * N + k + 1) * Bq] for k in range(N)]
+    sh = ds["sharding"]
+    assert sh["timed_region_samples"] == [N * Bq, 3 * N * Bq] and sh["batches"] == 2 * N and sh["ranges_tile_the_region_without_overlap"] is True
+    assert sh["sum_of_rank_counts_equals_all_reduced"] is True and sh["sum_of_rank_counts"] == d["counts"]
+    assert all(r["own_counts"]["samples"] == 2 * Bq for r in ds["ranks"]) and len({r["own_counts"]["flagged"] for r in ds["ranks"]}) > 1
     res1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", str(N * Bq),
                            "--p", "0.1", "--cpu-sample", "0", "--no-extras", "--no-build"], stdout=subprocess.PIPE,
                           stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
@@ -387,8 +414,8 @@ def test_bench_starts_its_own_ranks():
     assert res1.returncode == 0, res1.stderr[-2000:]
     d1 = json.loads([l for l in res1.stdout.splitlines() if l.strip()][0])
     assert d1["counts"] == d["counts"] and d["counts"]["block_errors"] > 0
-    # --no-literal (profiled runs): no literal-forms region, no forms_agreement decode — and the line says so with nulls
-    assert d1["literal_forms"] is None and d1["forms_agreement"] is None and d["literal_forms"]["value"] > 0
+    # --no-literal / --no-other-forms (profiled runs): no other-forms region, no forms_agreement decode — and the line says so with a null
+    assert d1["reassociated_forms"] is None and d1["literal_forms"]["value"] == d1["value"] and d["literal_forms"]["value"] > 0
 
 
 @pytest.mark.gpu

@@ -15,7 +15,7 @@ import zlib
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, WEIGHTS_882, code, llr_const, oracle_library_forms
+from helpers import GOLDEN, LIBRARY_BP4_SHARED_LSE, LIBRARY_GNN_FACTORED, WEIGHTS_882, code, llr_const, oracle_library_forms
 
 SEED = 0x5EED
 LLR_TOL = 1e-4  # north star: "LLRs within 1e-4"
@@ -49,19 +49,24 @@ class _Oracle:
     def syndrome(self, ex, ez):
         return self.g.syndrome(ex, ez)
 
-    def bp4(self, sx, sz, it, factor, L0=None, llr_ch=None, lse=1):
+    def bp4(self, sx, sz, it, factor, L0=None, llr_ch=None, lse=LIBRARY_BP4_SHARED_LSE):
         self.g.set_vn_shared_lse(lse)
         try:
             return self.g.bp4_decode(sx, sz, it, "boxplus-phi", factor, llr_const=0.0 if L0 is None else L0, llr_ch=llr_ch)
         finally:
-            self.g.set_vn_shared_lse(1)
+            self.g.set_vn_shared_lse(LIBRARY_BP4_SHARED_LSE)
 
     def gnn(self, w, order, llr, lhx, lhz, sx, sz):
         self.g.set_gnn_order(order)
         try:
             return self.g.feedback_gnn(w, llr, lhx, lhz, sx, sz)
         finally:
-            self.g.set_gnn_order(1)
+            self.g.set_gnn_order(LIBRARY_GNN_FACTORED)
+
+    def forms(self, reassociated):
+        assert (LIBRARY_GNN_FACTORED, LIBRARY_BP4_SHARED_LSE) == (False, False)
+        self.g.set_gnn_order(reassociated)
+        self.g.set_vn_shared_lse(reassociated)
 
     def sandwich(self, ex, ez, sx, sz, iters, w, L0):
         o = self.g.sandwich_decode(sx, sz, iters, [w] * (len(iters) - 1), L0, return_llr=True)
@@ -90,7 +95,7 @@ class _Gpu:
         sx, sz = self.g.syndrome(self._t(ex), self._t(ez))
         return sx.cpu().numpy(), sz.cpu().numpy()
 
-    def bp4(self, sx, sz, it, factor, L0=None, llr_ch=None, lse=1):
+    def bp4(self, sx, sz, it, factor, L0=None, llr_ch=None, lse=LIBRARY_BP4_SHARED_LSE):
         self.g.set_saturation_shortcut(it % 2 == 0)  # both dataflows are the same bits: alternate them across the cases
         self.g.set_bp4_shared_lse(lse)
         try:
@@ -98,7 +103,7 @@ class _Gpu:
                                   llr_ch=None if llr_ch is None else self._t(llr_ch))
         finally:
             self.g.set_saturation_shortcut(True)
-            self.g.set_bp4_shared_lse(True)
+            self.g.set_bp4_shared_lse(LIBRARY_BP4_SHARED_LSE)
         return {k: v.cpu().numpy() for k, v in o.items() if v is not None}
 
     def gnn(self, w, order, llr, lhx, lhz, sx, sz):
@@ -108,7 +113,11 @@ class _Gpu:
             return self.g.feedback_gnn(GnnWeights(w, self.g.device), self._t(llr), self._t(lhx), self._t(lhz), self._t(sx),
                                        self._t(sz)).cpu().numpy()
         finally:
-            self.g.set_gnn_factored(True)
+            self.g.set_gnn_factored(LIBRARY_GNN_FACTORED)
+
+    def forms(self, reassociated):
+        self.g.set_gnn_factored(reassociated)
+        self.g.set_bp4_shared_lse(reassociated)
 
     def sandwich(self, ex, ez, sx, sz, iters, w, L0):
         from feedback_gnn_amd.graph import GnnWeights
@@ -136,7 +145,7 @@ def _check_bp4_full(make):
         hx, hz = np.asarray(c.hx, dtype=np.int64), np.asarray(c.hz, dtype=np.int64)
         assert np.array_equal(sx, (ez.astype(np.int64) @ hx.T) % 2) and np.array_equal(sz, (ex.astype(np.int64) @ hz.T) % 2)
         # frozen bits: every float and every decision of the oracle's restatement, four iteration counts, two factors
-        for lse in (0, 1):  # the qubit update's log-sum-exp per edge (literal) / once per qubit and side (the default)
+        for lse in (0, 1):  # the qubit update's log-sum-exp per edge (literal, the default) / once per qubit and side (opt-in)
             for f in G["crc_factors"]:
                 for it in G["crc_iters"]:
                     o = impl.bp4(sx, sz, int(it), float(f), L0, lse=lse)
@@ -202,15 +211,22 @@ def _check_sandwich(make):
     c = code("ghp882")
     w = read_weight_list(WEIGHTS_882)
     L0 = llr_const(0.05)
-    # frozen bits: per-sample outcome bytes, rounds and CRCs of decisions / marginals, two sandwiches x 4 096 samples
+    # frozen bits: per-sample outcome bytes, rounds and CRCs of decisions / marginals, two sandwiches x 4 096 samples, in the library's
+    # default forms (the reference's formulas term by term) and in the opt-in re-associated forms (the round-3..5 fixture's values)
     for key, iters in (("ghp882_64-16", [64, 16]), ("ghp882_64-16-16-16", [64, 16, 16, 16])):
         B, first, p = int(G[f"{key}/B"]), int(G[f"{key}/first_sample"]), float(G[f"{key}/p"])
         ex, ez = impl.noise(p, first, B)
         sx, sz = impl.syndrome(ex, ez)
-        xh, zh, llr, rounds, fl = impl.sandwich(ex, ez, sx, sz, iters, w, L0)
-        assert np.array_equal(fl, G[f"{key}/flags"]), f"{impl.kind} {key}: {int((fl != G[f'{key}/flags']).sum())} samples end differently"
-        assert np.array_equal(rounds, G[f"{key}/rounds"])
-        assert _crc(xh, zh) == int(G[f"{key}/crc_decisions"]) and _crc(llr) == int(G[f"{key}/crc_llr"]), f"{impl.kind} {key}"
+        for sub, reassociated in (("", False), ("reassociated/", True)):
+            impl.forms(reassociated)
+            try:
+                xh, zh, llr, rounds, fl = impl.sandwich(ex, ez, sx, sz, iters, w, L0)
+            finally:
+                impl.forms(False)
+            assert np.array_equal(fl, G[f"{key}/{sub}flags"]), \
+                f"{impl.kind} {key} {sub}: {int((fl != G[f'{key}/{sub}flags']).sum())} samples end differently"
+            assert np.array_equal(rounds, G[f"{key}/{sub}rounds"])
+            assert _crc(xh, zh) == int(G[f"{key}/{sub}crc_decisions"]) and _crc(llr) == int(G[f"{key}/{sub}crc_llr"]), f"{impl.kind} {key} {sub}"
     # independent expectation: the NumPy composition (BP-64, flag, GNN, BP-16, masked merge, residual) on 256 samples
     first, p = int(G["numpy/first_sample"]), float(G["numpy/p"])
     B = G["numpy/rounds"].shape[0]
@@ -259,13 +275,13 @@ def _check_other_paths(kind):
                 try:
                     o = np_(gg.bp4_decode(to_gpu(sx), to_gpu(sz), it, cn, fac, llr_const=L0))
                 finally:
-                    gg.set_bp4_shared_lse(True)
+                    gg.set_bp4_shared_lse(LIBRARY_BP4_SHARED_LSE)
             else:
                 og.set_vn_shared_lse(lse)
                 try:
                     o = og.bp4_decode(sx, sz, it, cn, fac, llr_const=L0)
                 finally:
-                    og.set_vn_shared_lse(1)
+                    og.set_vn_shared_lse(LIBRARY_BP4_SHARED_LSE)
             assert _crc(o["llr"], o["x_hat"], o["z_hat"], o["x_logit"], o["z_logit"]) == int(G[f"bp4_{cn}_{fac}_{it}/crc_lse{lse}"]), (cn, lse)
     # binary syndrome BP on the hx graph
     e = og.bsc_noise(SEED, 0.04, first, B) if kind == "oracle" else gg.bsc_noise(SEED, 0.04, first, B).cpu().numpy()
@@ -308,13 +324,13 @@ def _check_other_paths(kind):
             try:
                 o = np_(gg.gnn_bp4_decode(GnnBp4Weights(w0, gg.device), to_gpu(sx[:6]), to_gpu(sz[:6]), 5))
             finally:
-                gg.set_gnn_factored(True)
+                gg.set_gnn_factored(LIBRARY_GNN_FACTORED)
         else:
             og.set_gnn_order(order)
             try:
                 o = og.gnn_bp4(w0, sx[:6], sz[:6], 5)
             finally:
-                og.set_gnn_order(1)
+                og.set_gnn_order(LIBRARY_GNN_FACTORED)
         assert _crc(*[o[k] for k in keys]) == int(G[f"gnnbp4/crc_order{order}"]), order
     if kind == "gpu":
         inv_r = {v: k for k, v in REDUCE_OPS.items()}

@@ -459,7 +459,7 @@ def test_options_round_trip_and_unknown_ids_are_refused():
     g.set_gnn_stream("always")
     assert g.gnn_stream == "always"
     g.set_gnn_stream(True)
-    assert g.gnn_stream is True and g.gnn_factored is True and g.bp4_shared_lse is True
+    assert g.gnn_stream is True and g.gnn_factored is False and g.bp4_shared_lse is False  # round 6: the re-associations are opt-in
     assert L.fgnn_graph_set_option(g.handle, 6, 3) == -1 and b"0, 1 or 2" in L.fgnn_last_error()
 
 
@@ -635,11 +635,12 @@ def test_cal_logit_and_the_rest_of_the_decoder_surface():
 def test_pauli_channel_in_the_references_calling_convention():
     """`Pauli(wt=False)([cx, cz, px, py, pz])` (pauli.py:72-117, as feedback_gnn.py:298-300 and bp_osd.py:107-109 call it): the
     depolarizing split on a `[bs, n]` shape taken from `cx`, no graph needed — the same Philox samples as the native call and the
-    oracle; `cz` given -> (y_x, y_z, noise_x, noise_z); `wt=True` -> exactly `wt` errors per row; other (px, py, pz) are refused."""
+    oracle; `cz` given -> (y_x, y_z, noise_x, noise_z); `wt=True` -> exactly `wt` errors per row; any other (px, py, pz) is the general
+    channel of pauli.py:98-108 (fgnn_pauli_noise_xyz) and equals the oracle's and NumPy's restatement of it."""
     c = code("ghp882")
     B, p = 50, 0.09
     og = oracle_library_forms("ghp882")
-    ch = F.Pauli(wt=False)
+    ch = F.Pauli(wt=False, seed=SEED)
     nx, nz = ch([torch.zeros((B, c.N)), None, 2 * p / 3, p / 3, 2 * p / 3])
     ex, ez = og.pauli_noise(SEED, p, 0, B)
     assert nx.dtype == torch.bool and np.array_equal(nx.cpu().numpy(), ex.astype(bool)) and np.array_equal(nz.cpu().numpy(), ez.astype(bool))
@@ -648,12 +649,34 @@ def test_pauli_channel_in_the_references_calling_convention():
     ex2, ez2 = og.pauli_noise(SEED, p, B, B)
     assert np.array_equal(nx2.cpu().numpy(), ex2.astype(bool)) and torch.equal(yx, cx ^ nx2) and torch.equal(yz, nz2)
     from helpers import gpu_graph
-    native = F.Pauli(gpu_graph("ghp882"))(B, p, 0)
+    native = F.Pauli(gpu_graph("ghp882"), seed=SEED)(B, p, 0)
     assert torch.equal(native[0].bool(), nx) and torch.equal(native[1].bool(), nz)
     wx, wz = F.Pauli(wt=True)([torch.zeros((B, c.N)), None, 7])
     assert ((wx | wz).sum(1) == 7).all()
-    with pytest.raises(NotImplementedError):
-        ch([torch.zeros((B, c.N)), None, 0.05, 0.0, 0.0])  # a pure bit-flip channel is not the path's channel
+    # any other triple is taken as pauli.py:98-108 takes it (round 6): a pure bit-flip channel, an asymmetric one — the oracle's
+    # restatement on the next samples of the channel's stream, and NumPy's own float32 comparisons on the same Philox words
+    from test_oracle_kat import numpy_pauli_xyz
+    pos = 2 * B
+    for triple in ((0.05, 0.0, 0.0), (0.11, 0.02, 0.05)):
+        tx, tz = ch([torch.zeros((B, c.N)), None, *triple])
+        ox, oz = og.pauli_noise_xyz(SEED, *triple, pos, B)
+        assert np.array_equal(tx.cpu().numpy(), ox.astype(bool)) and np.array_equal(tz.cpu().numpy(), oz.astype(bool)), triple
+        rx, rz = numpy_pauli_xyz(SEED, *triple, pos, 3, c.N)
+        assert np.array_equal(ox[:3], rx) and np.array_equal(oz[:3], rz)
+        pos += B
+    assert not ch([torch.zeros((B, c.N)), None, 0.05, 0.0, 0.0])[1].any()  # px only: no Z component anywhere
+    gg = gpu_graph("ghp882")
+    big = gg.pauli_noise_xyz(SEED, 0.11, 0.02, 0.05, (1 << 32) - 100, 4096)  # a full launch across the 32-bit counter boundary
+    obig = og.pauli_noise_xyz(SEED, 0.11, 0.02, 0.05, (1 << 32) - 100, 4096)
+    assert np.array_equal(big[0].cpu().numpy(), obig[0]) and np.array_equal(big[1].cpu().numpy(), obig[1])
+    with pytest.raises(ValueError):
+        gg.pauli_noise_xyz(SEED, float("nan"), 0.0, 0.0, 0, 4)
+    # seed-less channels do not replay each other (the reference's tf.random never repeats); an explicit seed reproduces
+    a, b2 = F.Pauli(wt=False), F.Pauli(wt=False)
+    assert a.seed != b2.seed
+    s1 = F.Pauli(seed=123)([torch.zeros((4, c.N)), None, 0.3, 0.1, 0.3])
+    s2 = F.Pauli(seed=123)([torch.zeros((4, c.N)), None, 0.3, 0.1, 0.3])
+    assert torch.equal(s1[0], s2[0]) and torch.equal(s1[1], s2[1])
 
 
 @pytest.mark.parametrize("rank,world", [(0, 1), (1, 3)])
@@ -682,6 +705,21 @@ def test_mc_graph_replays_equal_the_same_number_of_mc_steps(rank, world):
         eager.mc_step(B, p, ce)
     torch.cuda.synchronize()
     assert cg.tolist() == ce.tolist() and graphed._next_sample == eager._next_sample
+    # advisor (round 5): a LARGER batch on the same model re-binds the model's workspace; the graph owns its own (replay.workspace) and
+    # pins the weights it captured, so replays after the growth — and after the old tensor has gone back to the allocator and been
+    # overwritten — still add exactly what eager steps add
+    assert replay.workspace is not graphed._workspaces[0] and len(replay.weights) == 1 and replay.counts is cg
+    before = replay.workspace.data_ptr()
+    graphed.mc_steps(B, p, 4, torch.zeros(3, dtype=torch.int64, device="cuda"), torch.zeros((4, 3), dtype=torch.int64, device="cuda"))
+    for _ in range(4):
+        eager.mc_step(B, p, torch.zeros(3, dtype=torch.int64, device="cuda"))
+    junk = [torch.full((1 << 22,), 0x7f, dtype=torch.uint8, device="cuda") for _ in range(8)]  # recycle freed blocks
+    replay()
+    for _ in range(K):
+        eager.mc_step(B, p, ce)
+    torch.cuda.synchronize()
+    del junk
+    assert replay.workspace.data_ptr() == before and cg.tolist() == ce.tolist() and graphed._next_sample == eager._next_sample
     with pytest.raises(ValueError):
         _model(c, [32, 8], compact=True).mc_graph(B, p, K, cg)
     # the entry point the captured loop stands on: the stream position read on the device (fgnn_pauli_noise_dev) against the oracle

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import WEIGHTS_882, code, gpu_graph, llr_const, oracle_library_forms, oracle_literal_forms, to_gpu
+from helpers import LIBRARY_BP4_SHARED_LSE, WEIGHTS_882, code, gpu_graph, llr_const, oracle_library_forms, oracle_literal_forms, to_gpu
 
 pytestmark = pytest.mark.gpu
 SEED = 0x5EED
@@ -61,7 +61,7 @@ def test_literal_form_and_sandwich_on_a_code_beyond_the_lds_budget():
         o = ol.bp4_decode(sx, sz, 5, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
         g = gg.bp4_decode(to_gpu(sx), to_gpu(sz), 5, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
     finally:
-        gg.set_bp4_shared_lse(True)
+        gg.set_bp4_shared_lse(LIBRARY_BP4_SHARED_LSE)
     for k in ("llr", "x_hat", "z_hat", "x_logit", "z_logit"):
         assert np.array_equal(o[k], g[k].cpu().numpy()), k
     w = read_weight_list(WEIGHTS_882)

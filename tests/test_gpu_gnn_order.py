@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import WEIGHTS_882, WEIGHTS_1270, code, gpu_graph, llr_const, oracle_library_forms, to_gpu
+from helpers import LIBRARY_GNN_FACTORED, WEIGHTS_882, WEIGHTS_1270, code, gpu_graph, llr_const, oracle_library_forms, to_gpu
 
 pytestmark = pytest.mark.gpu
 
@@ -171,7 +171,7 @@ def test_kernel_choice_by_launch_size_gives_the_same_bits():
                 assert torch.equal(outs[False, n], outs[True, n]) and torch.equal(outs[True, n], outs["always", n]), (fact, n)
     finally:
         gg.set_gnn_stream(True)
-        gg.set_gnn_factored(True)
+        gg.set_gnn_factored(LIBRARY_GNN_FACTORED)
     with pytest.raises(Exception, match="0, 1 or 2"):
         from feedback_gnn_amd import _lib
         _lib.check(_lib.lib().fgnn_graph_set_option(gg.handle, 6, 3))

@@ -1,22 +1,23 @@
-"""The library's DEFAULT operation sequence against the reference's formulas term by term, sample by sample.
+"""The reference's formulas term by term (the library DEFAULT since round 6) and the two opt-in re-associations, sample by sample.
 
-libfgnn_hip runs two re-associations by default (include/fgnn.h: FGNN_OPT_BP4_SHARED_LSE, FGNN_OPT_GNN_FACTORED); the default parity
-tests therefore check "re-associated kernel == re-associated oracle" (helpers.oracle_library_forms).  This file holds the other two
-sides of the triangle:
+libfgnn_hip evaluates decoding_q.py:254-273 (one reduce_logsumexp per edge) and feedback_gnn.py:175-184 (one Dense per edge) term by
+term unless a caller switches on FGNN_OPT_BP4_SHARED_LSE / FGNN_OPT_GNN_FACTORED (include/fgnn.h).  The default parity tests check
+"default kernel == literal oracle" (helpers.oracle_library_forms); tests/test_gpu_bp4_shared_lse.py and test_gpu_gnn_order.py check each
+option on and off against the oracle's restatement of that form.  This file holds:
 
-  * the kernels with both options OFF equal the oracle's LITERAL restatement (decoding_q.py:254-273 one reduce_logsumexp per edge,
-    feedback_gnn.py:175-184 one Dense per edge) bit for bit through the whole sandwich — helpers.oracle_literal_forms;
-  * at the benchmark's operating point (BASELINE.json configs[2]: [[882,24]], BP4-64 + G + BP4-16, p = 0.01, 65 536 codewords) the
-    default forms give the SAME answers as the literal forms per sample: not one differing decision, marginals within the north-star
-    tolerance 1e-4 on every sample the decoder solves;
-  * in the waterfall (p = 0.05) they are the same decoder only statistically; the per-sample rates are recorded and bounded here so that
-    the documentation (include/fgnn.h, README) cannot drift from what the kernels do.
+  * the kernels with both options OFF (set explicitly) equal the oracle's LITERAL restatement bit for bit through the whole sandwich;
+  * what a caller who switches both options ON gets, per sample, against the default: MEASURED RATES on several windows of the sample
+    stream — including the window the round-5 driver run timed, where one solved sample sits at 1.03e-4 — with honest bounds.  They are
+    not guarantees: the re-associated forms are the reference's decoder statistically (include/fgnn.h), which is why they are opt-in;
+  * in the waterfall (p = 0.05) the per-sample rates are recorded and bounded so that the documentation (include/fgnn.h, README) cannot
+    drift from what the kernels do.
 """
 import numpy as np
 import pytest
 import torch
 
-from helpers import WEIGHTS_882, WEIGHTS_1270, code, gpu_graph, llr_const, oracle_library_forms, oracle_literal_forms, to_gpu
+from helpers import (LIBRARY_BP4_SHARED_LSE, LIBRARY_GNN_FACTORED, WEIGHTS_882, WEIGHTS_1270, code, gpu_graph, llr_const, oracle_library_forms,
+                     oracle_literal_forms, oracle_reassociated_forms, to_gpu)
 
 pytestmark = pytest.mark.gpu
 SEED = 0x5EED
@@ -68,52 +69,69 @@ def test_literal_kernels_equal_the_literal_oracle_through_the_sandwich(name, wfi
             assert np.array_equal(o["x_hat"], g["x_hat"].cpu().numpy()) and np.array_equal(o["z_hat"], g["z_hat"].cpu().numpy())
             assert np.array_equal(o["rounds"], g["rounds"].cpu().numpy())
             assert np.array_equal(o["llr"], g["llr"].cpu().numpy())
-    # and the library-forms oracle is a different restatement: in the waterfall its marginals are not the literal ones
+    # the library's default IS this restatement ...
+    og_def = oracle_library_forms(name)
+    assert (og_def.gnn_factored, og_def.vn_shared_lse) == (LIBRARY_GNN_FACTORED, LIBRARY_BP4_SHARED_LSE) == (False, False)
+    # ... and the re-associated oracle is a different one: in the waterfall its marginals are not the literal ones
     if p >= 0.06:
-        o2 = oracle_library_forms(name).sandwich_decode(sx, sz, iters, [w] * (nl - 1), llr_const(0.05), return_llr=True)
+        o2 = oracle_reassociated_forms(name).sandwich_decode(sx, sz, iters, [w] * (nl - 1), llr_const(0.05), return_llr=True)
         assert not np.array_equal(o["llr"], o2["llr"])
 
 
-def test_default_forms_agree_with_the_literal_forms_per_sample_at_the_benchmark_point():
-    """BASELINE configs[2] at full size: p = 0.01, 65 536 codewords, (64, G, 16), fixed dataflow.  Default vs literal forms: no sample
-    with a different final decision; marginals of the last decoder within 1e-4 on every sample either form solves (measured: 7.6e-6);
-    the handful of samples BP leaves flagged (measured: 1 of 65 536, under both forms) are the only ones whose marginals may differ
-    by more, and even they end on the same decisions."""
+# windows of the global sample stream (first sample, in batches of 65 536): the first batch, the round-5 driver's timed batch
+# (W = 5 warm-up steps: samples 327 680 .. 393 215, one solved sample at 1.03e-4 there), and six more
+WINDOWS_882 = (0, 5, 1, 2, 3, 17, 100, 1000)
+
+
+def test_reassociated_forms_against_the_default_at_the_benchmark_point_measured_rates():
+    """BASELINE configs[2] at full size: p = 0.01, 65 536 codewords per window, (64, G, 16), fixed dataflow, eight windows of the sample
+    stream.  Opt-in re-associated forms vs the default (literal) forms.  These are MEASURED RATES, NOT GUARANTEES: per window at most one
+    sample with a different final decision and at most two SOLVED samples whose marginals are further apart than the north-star tolerance
+    1e-4 (8.4 M samples: 3 differing decisions, 40 solved samples beyond 1e-4 — profiles/r4_forms_agreement_8M.json; the driver's round-5
+    window holds one at 1.03e-4).  A universal "within 1e-4 on every solved sample" does not hold and is not asserted."""
     name, B = "ghp882", 65536
     gg = gpu_graph(name)
     _, gw = _weights(WEIGHTS_882, gg)
-    ex, ez = gg.pauli_noise(SEED, 0.01, 0, B)
-    sx, sz = gg.syndrome(ex, ez)
     gg.set_saturation_shortcut(False)
+    tot = dict(decisions_differ=0, samples_gt_1e_4_solved=0, flagged_in_one_form_only=0)
     try:
-        r = gg.forms_agreement(sx, sz, [64, 16], [gw], llr_const(0.05))
+        for win in WINDOWS_882:
+            ex, ez = gg.pauli_noise(SEED, 0.01, win * B, B)
+            sx, sz = gg.syndrome(ex, ez)
+            r = gg.forms_agreement(sx, sz, [64, 16], [gw], llr_const(0.05))
+            print(f"forms agreement at p = 0.01, window {win}:", {k: r[k] for k in ("decisions_differ", "max_abs_dllr_solved", "samples_gt_1e_4_solved",
+                                                                                   "samples_gt_1e_4", "flagged_reassociated", "flagged_literal")})
+            assert r["samples"] == B and r["decisions_differ"] <= 1, (win, r)
+            assert r["samples_gt_1e_4_solved"] <= 2, (win, r)
+            assert r["flagged_in_one_form_only"] <= 1 and max(r["flagged_reassociated"], r["flagged_literal"]) <= 8, (win, r)
+            assert r["first_decoder"]["decisions_differ"] <= 1, (win, r)
+            for k in tot:
+                tot[k] += r[k]
     finally:
         gg.set_saturation_shortcut(True)
-    assert gg.gnn_factored and gg.bp4_shared_lse  # settings restored
-    assert r["samples"] == B and r["decisions_differ"] == 0, r
-    assert r["max_abs_dllr_solved"] <= 1e-4 and r["samples_gt_1e_4_solved"] == 0, r
-    assert r["flagged_in_one_form_only"] == 0 and r["flagged_default"] == r["flagged_literal"] <= 8, r
-    assert r["samples_gt_1e_4"] <= r["flagged_default"], r  # only unsolved samples may be further apart
-    assert r["first_decoder"]["decisions_differ"] == 0, r
+    assert (gg.gnn_factored, gg.bp4_shared_lse) == (LIBRARY_GNN_FACTORED, LIBRARY_BP4_SHARED_LSE)  # settings restored
+    assert tot["decisions_differ"] <= 2 and tot["samples_gt_1e_4_solved"] <= 6, tot  # 524 288 samples; 8.4 M hold 3 and 40
 
 
-def test_default_forms_agree_with_the_literal_forms_on_the_c4_code_at_p_001():
-    """The same on the configs[3] shard shape ([[1270,28]], (64, G, 64), 32 768 codewords, p = 0.01): measured 0 / 7.6e-6 / 0 flagged."""
+def test_reassociated_forms_against_the_default_on_the_c4_code_at_p_001_measured_rates():
+    """The same on the configs[3] shard shape ([[1270,28]], (64, G, 64), 32 768 codewords per window, p = 0.01), four windows; 8.4 M samples
+    hold 6 differing decisions and 4 solved samples beyond 1e-4 (profiles/r4_forms_agreement_8M.json).  Measured rates, not guarantees."""
     name, B = "ghp1270", 32768
     gg = gpu_graph(name)
     _, gw = _weights(WEIGHTS_1270, gg)
-    ex, ez = gg.pauli_noise(SEED, 0.01, 0, B)
-    sx, sz = gg.syndrome(ex, ez)
     gg.set_saturation_shortcut(False)
     try:
-        r = gg.forms_agreement(sx, sz, [64, 64], [gw], llr_const(0.05))
+        for win in (0, 3, 24, 500):
+            ex, ez = gg.pauli_noise(SEED, 0.01, win * B, B)
+            sx, sz = gg.syndrome(ex, ez)
+            r = gg.forms_agreement(sx, sz, [64, 64], [gw], llr_const(0.05))
+            assert r["decisions_differ"] <= 1 and r["samples_gt_1e_4_solved"] <= 2 and r["flagged_in_one_form_only"] <= 1, (win, r)
     finally:
         gg.set_saturation_shortcut(True)
-    assert r["decisions_differ"] == 0 and r["max_abs_dllr_solved"] <= 1e-4 and r["flagged_in_one_form_only"] == 0, r
 
 
 def test_in_the_waterfall_the_two_forms_are_the_same_decoder_only_statistically():
-    """p = 0.05, 65 536 codewords of [[882,24]]: the forms differ by float32 rounding in the qubit update, BP's transient amplifies that
+    """p = 0.05, 65 536 codewords of [[882,24]]: the opt-in forms differ from the default by float32 rounding in the qubit update, BP's transient amplifies that
     on the samples that take long to converge, and a fraction of the samples ends on a different (equally valid) representative.
     Measured (profiles/r4_forms_agreement.json): 74 of 65 536 decisions differ (0.11 %), 213 samples beyond 1e-4, 12 vs 13 left flagged.
     The bounds below are what include/fgnn.h and README.md quote; the decoder's success is unchanged within binomial noise."""
@@ -126,4 +144,4 @@ def test_in_the_waterfall_the_two_forms_are_the_same_decoder_only_statistically(
     print("forms agreement at p = 0.05:", r)
     assert 0 < r["decisions_differ"] <= 0.005 * B, r          # measured 0.11 %: not identical, and not more than half a per cent
     assert r["samples_gt_1e_4"] <= 0.01 * B, r
-    assert abs(r["flagged_default"] - r["flagged_literal"]) <= 6 * max(1.0, r["flagged_in_one_form_only"]) ** 0.5 + 1, r
+    assert abs(r["flagged_reassociated"] - r["flagged_literal"]) <= 6 * max(1.0, r["flagged_in_one_form_only"]) ** 0.5 + 1, r

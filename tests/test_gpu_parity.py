@@ -11,7 +11,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import WEIGHTS_882, WEIGHTS_1270, code, gpu_graph, llr_const, oracle_library_forms, to_gpu
+from helpers import (LIBRARY_BP4_SHARED_LSE, LIBRARY_GNN_FACTORED, WEIGHTS_882, WEIGHTS_1270, code, gpu_graph, llr_const,
+                     oracle_library_forms, to_gpu)
 
 pytestmark = pytest.mark.gpu
 
@@ -459,7 +460,7 @@ def test_general_gnn_bp4_bit_exact(name, cfg):
         try:
             sp = gg.gnn_bp4_decode(GnnBp4Weights(w, gg.device), tx, tz, iters)
         finally:
-            gg.set_gnn_factored(True)
+            gg.set_gnn_factored(LIBRARY_GNN_FACTORED)
         assert torch.equal(sp["llr"], g["llr"]) and torch.equal(sp["x_logit_all"], g["x_logit_all"])
 
 
@@ -887,14 +888,15 @@ def test_general_feedback_gnn_bit_exact(name, cfg):
     got = gg.feedback_gnn(gw, to_gpu(o["llr"]), to_gpu(o["z_logit"]), to_gpu(o["x_logit"]), tx, tz).cpu().numpy()
     assert np.array_equal(ref, got), np.abs(ref - got).max()
     if cfg == GEN_CONFIGS[0]:  # the shipped setting: the runtime-shaped kernel (always the literal association) and the specialised
-        # kernels in the literal order agree bit for bit; the default (factored) order is the same function with other roundings
+        # kernels in the literal order (the library default) agree bit for bit; the opt-in factored order is the same function with other roundings
         args = (GnnWeights(w, gg.device), to_gpu(o["llr"]), to_gpu(o["z_logit"]), to_gpu(o["x_logit"]), tx, tz)
-        fact = gg.feedback_gnn(*args).cpu().numpy()
-        gg.set_gnn_factored(False)
+        gg.set_gnn_factored(True)
         try:
+            fact = gg.feedback_gnn(*args).cpu().numpy()
+            gg.set_gnn_factored(False)
             sp = gg.feedback_gnn(*args).cpu().numpy()
         finally:
-            gg.set_gnn_factored(True)
+            gg.set_gnn_factored(LIBRARY_GNN_FACTORED)
         assert np.array_equal(got, sp)
         assert np.abs(fact - sp).max() <= 1e-5 * max(1.0, np.abs(sp).max())
 
@@ -1026,8 +1028,8 @@ def test_random_codes_fuzz_every_runtime_degree_kernel():
                                                    return_msgs=True), f"{tag} {cn} lse={lse} restart")
                 tr = gg.bp4_decode_trace(tx, tz, it, cn, fac, llr_ch=to_gpu(llr), msg_init=tuple(to_gpu(x) for x in init), want_tape=True)
                 assert np.array_equal(o2["x_logit"], tr["x_logit"][it].cpu().numpy()) and np.array_equal(o2["msg_z"], tr["tape_z"][it].cpu().numpy()), tag
-        og.set_vn_shared_lse(1)
-        gg.set_bp4_shared_lse(True)
+        og.set_vn_shared_lse(LIBRARY_BP4_SHARED_LSE)
+        gg.set_bp4_shared_lse(LIBRARY_BP4_SHARED_LSE)
         o = og.bp4_decode(sx, sz, 6, "boxplus-phi", 1.0, llr_const=L0)
         for order in (0, 1):
             og.set_gnn_order(order)
@@ -1039,5 +1041,5 @@ def test_random_codes_fuzz_every_runtime_degree_kernel():
             gb = gg.gnn_bp4_decode(GnnBp4Weights(wb, gg.device), tx, tz, 2)
             for k in ("llr", "x_logit_all", "z_logit_all", "x_hat", "z_hat"):
                 assert np.array_equal(rb[k], gb[k].cpu().numpy()), f"{tag} GNN_BP4 order={order} {k}"
-        og.set_gnn_order(1)
-        gg.set_gnn_factored(True)
+        og.set_gnn_order(LIBRARY_GNN_FACTORED)
+        gg.set_gnn_factored(LIBRARY_GNN_FACTORED)

@@ -43,6 +43,43 @@ def test_syndromes_and_noise_statistics():
     assert np.array_equal(e2x, ex[700:1000]) and np.array_equal(e2z, ez[700:1000])
 
 
+def numpy_pauli_xyz(seed, px, py, pz, first, B, n):
+    """Pauli.call (pauli.py:98-108) in NumPy float32 on the build's Philox stream: u = Uint32ToFloat(word q % 4 of block q // 4 of
+    sample first + b); noise_x = u < px (:103); noise_z = (u >= px - py) & (u < (px + pz) - py) (:104-106)."""
+    from oracle import oracle as O
+    px, py, pz = np.float32(px), np.float32(py), np.float32(pz)
+    u = np.empty((B, 4 * ((n + 3) // 4)), np.float32)
+    for b in range(B):
+        s = first + b
+        for blk in range((n + 3) // 4):
+            r = O.philox([s & 0xffffffff, s >> 32, blk, 0], [seed & 0xffffffff, seed >> 32])
+            u[b, 4 * blk:4 * blk + 4] = ((r >> np.uint32(9)) | np.uint32(0x3f800000)).view(np.float32) - np.float32(1)
+    u = u[:, :n]
+    return (u < px).astype(np.uint8), ((u >= px - py) & (u < (px + pz) - py)).astype(np.uint8)
+
+
+@pytest.mark.parametrize("triple", [(0.06, 0.03, 0.06), (0.11, 0.02, 0.05), (0.05, 0.0, 0.0), (0.0, 0.0, 0.08), (0.3, 0.3, 0.3)])
+def test_general_pauli_triple_vs_numpy_threshold_restatement(triple):
+    """Pauli.call takes ANY (px, py, pz) (pauli.py:98-108); the oracle's og_pauli_noise_xyz against NumPy's own float32 comparisons on
+    the same Philox words — asymmetric channel, pure bit-flip, pure phase-flip, pure Y — and the depolarizing entry point is the triple
+    (2p/3, p/3, 2p/3) formed in float32."""
+    g = oracle_library_forms("steane")
+    first, B = (1 << 32) - 3, 6  # crosses the 32-bit boundary of the sample counter
+    ex, ez = g.pauli_noise_xyz(SEED, *triple, first, B)
+    rx, rz = numpy_pauli_xyz(SEED, *triple, first, B, g.n)
+    assert np.array_equal(ex, rx) and np.array_equal(ez, rz)
+    # event rates on a larger draw: X = px - py, Y = py, Z = pz - py
+    g2 = oracle_library_forms("gb254")
+    ex, ez = g2.pauli_noise_xyz(SEED, *triple, 0, 2000)
+    px, py, pz = triple
+    for cnt, want in (((ex & ~ez & 1).sum(), px - py), ((ex & ez).sum(), py), ((~ex & ez & 1).sum(), pz - py)):
+        assert abs(cnt / ex.size - want) <= 5 * np.sqrt(max(want, 1e-6) / ex.size), (triple, cnt / ex.size, want)
+    p = np.float32(0.09)
+    a = g2.pauli_noise(SEED, p, 17, 300)
+    b = g2.pauli_noise_xyz(SEED, (np.float32(2) * p) / np.float32(3), p / np.float32(3), (np.float32(2) * p) / np.float32(3), 17, 300)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 @pytest.mark.parametrize("name,p,iters", [("ghp882", 0.05, 64), ("ghp882", 0.10, 32), ("gb48", 0.04, 16), ("rsurf3", 0.05, 20)])
 def test_c_oracle_vs_numpy_restatement(name, p, iters):
     """The C oracle (polynomial exp/log, scalar loops) against oracle/numpy_ref.py (NumPy exp/log,
@@ -219,7 +256,7 @@ def _gen_weights(cfg, seed=3):
 
 def test_general_feedback_gnn_oracle_equals_specialised_on_the_shipped_setting():
     """og_feedback_gnn_general (always the literal association: it serves every reduce_op) with (20, 40, 2, mean, tanh, bias) walks
-    the same float ops as og_feedback_gnn in the literal order; the factored order (the default) is the same function with other
+    the same float ops as og_feedback_gnn in the literal order (the default); the opt-in factored order is the same function with other
     roundings."""
     g = oracle_library_forms("gb48")
     ex, ez = g.pauli_noise(SEED, 0.06, 0, 9)
@@ -227,13 +264,13 @@ def test_general_feedback_gnn_oracle_equals_specialised_on_the_shipped_setting()
     o = g.bp4_decode(sx, sz, 5, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
     w = read_weight_list(WEIGHTS_882)
     b = g.feedback_gnn_general((20, 40, 2, 1, 1, 1), w, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
-    assert g.gnn_factored
-    f = g.feedback_gnn(w, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
-    g.set_gnn_order(0)
+    assert not g.gnn_factored
+    a = g.feedback_gnn(w, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
+    g.set_gnn_order(1)
     try:
-        a = g.feedback_gnn(w, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
+        f = g.feedback_gnn(w, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
     finally:
-        g.set_gnn_order(1)
+        g.set_gnn_order(0)  # the library default
     assert np.array_equal(a, b)
     assert 0 < np.abs(f - a).max() <= 2e-6
 
@@ -283,7 +320,7 @@ def test_general_gnn_bp4_oracle_equals_specialised_on_the_benchmark_setting():
     try:
         a = g.gnn_bp4(w, sx, sz, 4)
     finally:
-        g.set_gnn_order(1)
+        g.set_gnn_order(0)  # the library default
     for k in a:
         assert np.array_equal(a[k], b[k]), k
 
@@ -307,11 +344,11 @@ def test_general_gnn_bp4_oracle_vs_numpy_restatement(name, cfg):
 
 
 def test_the_oracle_starts_literal_and_a_checker_must_name_its_forms():
-    """Round 4: the C oracle is created as the LITERAL restatement of the reference (one log-sum-exp per edge, decoding_q.py:254-273;
-    one Dense per edge, feedback_gnn.py:175-184); the re-associated forms libfgnn_hip runs by default are restated next to it and have
-    to be asked for.  OracleGraph has no default for `forms`: every checker says which restatement it compares against.  The two are
-    different float32 operation sequences of the same function: equal decisions on an easy batch, marginals that differ in the last
-    bits after ONE iteration from non-trivial messages."""
+    """The C oracle is created as the LITERAL restatement of the reference (one log-sum-exp per edge, decoding_q.py:254-273; one Dense
+    per edge, feedback_gnn.py:175-184) — since round 6 also what libfgnn_hip runs by default ("library-default"); the library's two
+    opt-in re-associations are restated next to it ("reassociated") and have to be asked for.  OracleGraph has no default for `forms`:
+    every checker says which restatement it compares against.  The two are different float32 operation sequences of the same
+    function: equal decisions on an easy batch, marginals that differ in the last bits after ONE iteration from non-trivial messages."""
     from oracle.oracle import OracleGraph
     from helpers import WEIGHTS_882
     from feedback_gnn_amd.weights_io import read_weight_list
@@ -320,8 +357,9 @@ def test_the_oracle_starts_literal_and_a_checker_must_name_its_forms():
         OracleGraph(c)
     with pytest.raises(ValueError):
         OracleGraph(c, forms="fast")
-    lit, lib = OracleGraph(c, forms="literal"), OracleGraph(c, forms="library-default")
-    assert (lit.gnn_factored, lit.vn_shared_lse, lib.gnn_factored, lib.vn_shared_lse) == (False, False, True, True)
+    lit, dflt, lib = OracleGraph(c, forms="literal"), OracleGraph(c, forms="library-default"), OracleGraph(c, forms="reassociated")
+    assert (lit.gnn_factored, lit.vn_shared_lse, dflt.gnn_factored, dflt.vn_shared_lse, lib.gnn_factored, lib.vn_shared_lse) == \
+        (False, False, False, False, True, True)
     ex, ez = lit.pauli_noise(0x5EED, 0.03, 0, 64)
     sx, sz = lit.syndrome(ex, ez)
     rng = np.random.RandomState(1)
