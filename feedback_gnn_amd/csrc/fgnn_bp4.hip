@@ -32,9 +32,6 @@
 #ifndef FGNN_PHI_STAGE
 #define FGNN_PHI_STAGE 1  // phi evaluations staged together in the regular check-node update (phi_n), must divide DC
 #endif
-#ifndef FGNN_LSE_STAGE
-#define FGNN_LSE_STAGE 0  // literal qubit update of the regular kernel: 0 = one fg_lse2 per edge in turn, 1 = the edges of a side staged (lse2_n)
-#endif
 
 namespace {
 
@@ -282,49 +279,6 @@ __device__ __forceinline__ void phi_n(const float (&x)[N], float (&out)[N])
     }
 }
 
-// N evaluations of fg_lse2 (fgnn_math.h) — the per-edge reduce_logsumexp of the LITERAL qubit update (decoding_q.py:266, :271) — laid
-// out like phi_n: (A) |a - b|, the clamp, exp, 1 + y and the table address of every value; (B) the N two-dword table reads; (C) the
-// remainders, polynomials and the + max(a, b).  Every value goes through exactly the float operations of fg_lse2 in the same order:
-// -min(d, 20) is formed as max(-d, -20) (the same float) and made opaque to the compiler, so that the exponential's range reduction
-// issues as full-rate VOP2 literal forms instead of a VOP3 with a negated source and the constant in an SGPR (half rate on gfx950).
-template <int N, bool HWT = false>
-__device__ __forceinline__ void lse2_n(const float (&a)[N], const float (&b)[N], float (&out)[N])
-{
-    if constexpr (HWT) {
-#pragma unroll
-        for (int k = 0; k < N; ++k) out[k] = Mx<true>::lse2(a[k], b[k]);
-        return;
-    }
-    const float* tab = fg_log_tab();
-    float x1[N];
-    uint32_t eb[N], j[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        float nd = FG_MAX(-FG_ABS(a[k] - b[k]), -20.0f);  // = -min(|a - b|, 20)
-        asm volatile("" : "+v"(nd));
-        const float y = fg_exp(nd);
-        x1[k] = 1.0f + y;
-        const uint32_t w = fg_f2u(x1[k]) - FG_LOG_OFFS;  // fg_log(1 + y)
-        eb[k] = w & 0xff800000u;
-        j[k] = (w >> 18) & 31u;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    float rc[N], lc[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        rc[k] = tab[j[k]];
-        lc[k] = tab[32 + j[k]];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const float mm = fg_u2f(fg_f2u(x1[k]) - eb[k]);
-        const float r = FG_FMA(mm, rc[k], -1.0f);
-        const float lg = FG_FMA((float)(int32_t)eb[k], FG_LN2_S23, lc[k] + fg_log1p_small(r));
-        out[k] = lg + FG_MAX(a[k], b[k]);
-    }
-}
-
 // c->v update of one (DC-regular) check with every message in registers: the phi rule of the benchmark
 // configurations without the LDS round trip of the runtime-degree version.  Same float ops, same order.
 // Signs are carried as integer sign words: neg = (synd << 31) ^ bits(v_0) ^ ... (bit 31 = the parity of :398-399), and the
@@ -500,7 +454,8 @@ __device__ __forceinline__ float softplus_saturated(float t)
 // order; within a workgroup __syncthreads() orders the global stores of one phase before the loads of the next.
 // LSE: the form of the qubit update's log-sum-exp term — 0 = per edge (the reference's formulas term by term, decoding_q.py:254-273: the
 // library default), 1 = once per qubit and side (FGNN_OPT_BP4_SHARED_LSE), both compiled in for the (3,3,6)-regular phi kernels; 2 = either,
-// chosen by a.shared_lse at run time (every other instantiation).
+// chosen by a.shared_lse at run time (every other instantiation).  The compile-time forms run at the speed of the runtime flag (44.8 / 39.5
+// ms either way); what they buy is one kernel SYMBOL per form, so that a rocprofv3 trace or PMC pass prices each form by itself.
 template <int CN_TYPE, int DVX, int DVZ, int DC, bool OPT, bool HWT = false, int NQ = 0, bool TRACE = false, bool GMEM = false, int LSE = 2>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NQ > 0 ? FGNN_BP4_WAVES - 1 : FGNN_BP4_WAVES)))
 bp4_kernel(GraphDev g, BpArgs a)
@@ -719,20 +674,10 @@ bp4_kernel(GraphDev g, BpArgs a)
                         }
                         return;
                     }
-                    if constexpr (FGNN_LSE_STAGE != 0 && !HWT) {  // the edges of a side staged: same float operations, other schedule
-                        float ax[DVX], bx[DVX], ox[DVX], az[DVZ], bz[DVZ], oz[DVZ];
-#pragma unroll
-                        for (int k = 0; k < DVX; ++k) { ax[k] = -(Z - mx[k]); bx[k] = -(Y - mx[k]); }
-                        lse2_n<DVX>(ax, bx, ox);
-#pragma unroll
-                        for (int k = 0; k < DVX; ++k) px[k] = numx - ox[k];
-#pragma unroll
-                        for (int k = 0; k < DVZ; ++k) { az[k] = -(X - mz[k]); bz[k] = -(Y - mz[k]); }
-                        lse2_n<DVZ>(az, bz, oz);
-#pragma unroll
-                        for (int k = 0; k < DVZ; ++k) pz[k] = numz - oz[k];
-                        return;
-                    }
+                    // the reference's per-edge form (the library default).  Round 6, measured and NOT merged (profiles/
+                    // r6_literal_kernel_attempts.txt): the three edges of a side staged like phi_n (exps, then the table reads, then the
+                    // polynomials) with the range reduction forced onto full-rate VOP2 forms — BP4-64 44.97 ms against 45.06 ([[882,24]] x
+                    // 65 536, run-to-run +-0.2), as in round 2 (45.30 against 45.36): at seven waves per SIMD nothing is left to hide
 #pragma unroll
                     for (int k = 0; k < DVX; ++k) {
                         const float Ze = Z - mx[k], Ye = Y - mx[k];

@@ -391,10 +391,7 @@ static_assert(HID % EMB_U == 0 && EMB_U % 2 == 0, "the embed MLP walks its hidde
 #ifndef FGNN_GNNS_LIT_WAVES
 #define FGNN_GNNS_LIT_WAVES 5  // the literal association keeps one more 20-wide accumulator alive per lane
 #endif
-#ifndef FGNN_GNNS_LIT_PAIR
-#define FGNN_GNNS_LIT_PAIR 1  // literal association: two hidden units per loop trip, their first Dense as v_pk_fma_f32 on SGPR pairs (side_stream_literal_pair)
-#endif
-constexpr int PROW = 16;  // floats per row of WeightsDev::msg_pairs
+
 #define FGNN_GNNS_OCC __attribute__((amdgpu_waves_per_eu(FGNN_GNNS_WAVES, FGNN_GNNS_WAVES)))
 
 struct MsgRow {
@@ -450,6 +447,10 @@ __device__ __forceinline__ void side_stream(scalar_fp rows, scalar_fp b2, const 
 // ascending check order and divided by their number.  One lane per qubit, weights as scalar operands like side_stream; the edge loop
 // is a real loop (unrolled, the compiler interleaves the edges and spills a hundred registers).  Round 4: 12.9 ms against the MFMA
 // tiles' 14.7 on [[882,24]] x 65 536 (profiles/r4_gnn_literal_stream_ab.txt); with plain v_fmac for the second Dense it was 15.2.
+// Round 6, measured and NOT merged (profiles/r6_literal_kernel_attempts.txt): two hidden units per trip with the four-term first Dense
+// and the bias as v_pk_fma_f32 / v_pk_add_f32 on SGPR pairs (57 instead of 62 VALU instructions per two units and edge, two
+// independent tanh chains per trip, bit-equal): 13.18 ms against 12.97 ([[1270,28]] x 32 768: 9.42 against 9.25) — the loop waits on
+// its scalar weight loads either way and the five half-rate v_fmac it removes were not the bound.
 template <int DV>
 __device__ __forceinline__ void side_stream_literal(scalar_fp rows, scalar_fp b2, const float (&gv)[DV], float X, float Y, float Z,
                                                     float* __restrict__ feat)
@@ -477,51 +478,6 @@ __device__ __forceinline__ void side_stream_literal(scalar_fp rows, scalar_fp b2
             const f2 h = bc_lo(fg_tanh(a + r[4]));
 #pragma unroll
             for (int i = 0; i < MSG / 2; ++i) m[i] = pk_fma(h, w2[i], m[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < MSG / 2; ++i) {
-            const float m0 = m[i].x + b2[2 * i], m1 = m[i].y + b2[2 * i + 1];
-            feat[2 * i] = (e == 0) ? m0 : feat[2 * i] + m0;
-            feat[2 * i + 1] = (e == 0) ? m1 : feat[2 * i + 1] + m1;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MSG; ++i) feat[i] = DV == 3 ? fg_div3(feat[i]) : feat[i] / (float)DV;
-}
-
-// The literal side with TWO hidden units per loop trip (round 6).  side_stream_literal forms each unit's four-term first Dense as four
-// v_fmac with an SGPR multiplier and adds b1 from an SGPR: five half-rate instructions per unit and edge on gfx950 (a wave-uniform
-// operand of a scalar VALU instruction costs a second issue cycle pair, fgnn_pk.h).  Here units j and j + 1 share four v_pk_fma_f32 and
-// one v_pk_add_f32 whose weights W1[k][j], W1[k][j + 1] / b1[j], b1[j + 1] are SGPR pairs (WeightsDev::msg_pairs) and whose per-lane input
-// is broadcast to both halves by op_sel; the two tanh chains of a trip are independent and interleave.  Each half is the IEEE fma / add
-// of the one-unit form in the same order (k = 0..3 from 0, then + b1), the 40 -> 20 Dense still accumulates over ascending j: same bits.
-template <int DV>
-__device__ __forceinline__ void side_stream_literal_pair(scalar_fp rows, scalar_fp pairs, scalar_fp b2, const float (&gv)[DV], float X,
-                                                         float Y, float Z, float* __restrict__ feat)
-{
-#pragma unroll 1
-    for (int e = 0; e < DV; ++e) {
-        float ge = gv[0];
-#pragma unroll
-        for (int k = 1; k < DV; ++k) ge = e == k ? gv[k] : ge;
-        f2 m[MSG / 2];
-#pragma unroll
-        for (int i = 0; i < MSG / 2; ++i) m[i] = bc2(0.0f);
-#pragma unroll 1
-        for (int jp = 0; jp < HID / 2; ++jp) {
-            scalar_f2p pr = (scalar_f2p)(pairs + jp * PROW);
-            scalar_f2p w2a = (scalar_f2p)(rows + (2 * jp) * SROW + 8), w2b = (scalar_f2p)(rows + (2 * jp + 1) * SROW + 8);
-            f2 a = bc2(0.0f);
-            a = pk_fma(bc_lo(ge), pr[0], a);
-            a = pk_fma(bc_lo(X), pr[1], a);
-            a = pk_fma(bc_lo(Y), pr[2], a);
-            a = pk_fma(bc_lo(Z), pr[3], a);
-            a = a + pr[4];
-            const f2 h0 = bc_lo(fg_tanh(a.x)), h1 = bc_lo(fg_tanh(a.y));
-#pragma unroll
-            for (int i = 0; i < MSG / 2; ++i) m[i] = pk_fma(h0, w2a[i], m[i]);
-#pragma unroll
-            for (int i = 0; i < MSG / 2; ++i) m[i] = pk_fma(h1, w2b[i], m[i]);
         }
 #pragma unroll
         for (int i = 0; i < MSG / 2; ++i) {
@@ -620,15 +576,13 @@ gnn_stream_kernel(GraphDev g, WeightsDev w, GnnArgs a)
         // unit loop instead of inside it, where the wait would also cover the loop's weight loads
 #pragma unroll
         for (int k = 0; k < DV; ++k) asm volatile("" : "+v"(gv[k]));
-        if constexpr (LITERAL && FGNN_GNNS_LIT_PAIR) side_stream_literal_pair<DV>(mrx, as_scalar((const float*)__builtin_assume_aligned(w.msg_pairs[0], 64)), b2x, gv, X, Y, Z, feat);
-        else if constexpr (LITERAL) side_stream_literal<DV>(mrx, b2x, gv, X, Y, Z, feat);
+        if constexpr (LITERAL) side_stream_literal<DV>(mrx, b2x, gv, X, Y, Z, feat);
         else side_stream<DV>(mrx, b2x, gv, X, Y, Z, feat);
 #pragma unroll
         for (int k = 0; k < DV; ++k) gv[k] = gcn[g.m_x + g.vchk[g.E_x + v * DV + k]];
 #pragma unroll
         for (int k = 0; k < DV; ++k) asm volatile("" : "+v"(gv[k]));
-        if constexpr (LITERAL && FGNN_GNNS_LIT_PAIR) side_stream_literal_pair<DV>(mrz, as_scalar((const float*)__builtin_assume_aligned(w.msg_pairs[1], 64)), b2z, gv, X, Y, Z, feat + MSG);
-        else if constexpr (LITERAL) side_stream_literal<DV>(mrz, b2z, gv, X, Y, Z, feat + MSG);
+        if constexpr (LITERAL) side_stream_literal<DV>(mrz, b2z, gv, X, Y, Z, feat + MSG);
         else side_stream<DV>(mrz, b2z, gv, X, Y, Z, feat + MSG);
         // vn_embed_mlp Dense(40,tanh) on [m_x | m_z | X,Y,Z], then _llr_inv_embed Dense(3)  (:186)
         float o[3] = {0.0f, 0.0f, 0.0f};
@@ -809,23 +763,6 @@ extern "C" int fgnn_weights_create(const float* const host_arrays[12], int devic
             for (int i = 0; i < MSG; ++i) r[8 + i] = W2[j * MSG + i];
         }
     }
-    // per-pair rows of the literal association's first Dense (side_stream_literal_pair)
-    size_t off_mp[2];
-    for (int s = 0; s < 2; ++s) {
-        while (h.size() % 32) h.push_back(0.0f);
-        off_mp[s] = push((size_t)(HID / 2) * PROW);
-        const float* W1 = host_arrays[2 + 4 * s];
-        const float* B1 = host_arrays[3 + 4 * s];
-        for (int jp = 0; jp < HID / 2; ++jp) {
-            float* r = &h[off_mp[s] + (size_t)jp * PROW];
-            for (int k = 0; k < 4; ++k) {
-                r[2 * k] = W1[k * HID + 2 * jp];
-                r[2 * k + 1] = W1[k * HID + 2 * jp + 1];
-            }
-            r[8] = B1[2 * jp];
-            r[9] = B1[2 * jp + 1];
-        }
-    }
     while (h.size() % 32) h.push_back(0.0f);
     const size_t off_er = push((size_t)HID * EROW);
     for (int j = 0; j < HID; ++j) {
@@ -907,8 +844,6 @@ extern "C" int fgnn_weights_create(const float* const host_arrays[12], int devic
     w->d.lane_tab = base + off_tab;
     w->d.msg_rows[0] = base + off_mr[0];
     w->d.msg_rows[1] = base + off_mr[1];
-    w->d.msg_pairs[0] = base + off_mp[0];
-    w->d.msg_pairs[1] = base + off_mp[1];
     w->d.emb_rows = base + off_er;
     w->d.emb_quads = base + off_eq;
     *out = w;

@@ -78,7 +78,6 @@ struct WeightsDev {
     const float* bout;    // [4]
     const float* lane_tab;  // [132][64] per-lane MFMA operand / bias tables (fgnn_gnn.hip, mfma path)
     const float* msg_rows[2];  // [40][32] per hidden unit: W1[0..3][j], b1[j], 0,0,0, W2[j][0..19], 0 x 4 (gnn_stream_kernel)
-    const float* msg_pairs[2]; // [20][16] per two hidden units j, j+1: W1[k][j], W1[k][j+1] for k = 0..3, b1[j], b1[j+1], 0 x 6 (literal association)
     const float* emb_rows;     // [40][48] per hidden unit: We[0..42][j], be[j], Wout[j][0..2], 0
     const float* emb_quads;    // [10][192] per four hidden units j0..j0+3: We[k][j0..j0+3] for k = 0..42, be[j0..j0+3], Wout[j0+u][0..2] for u = 0..3, 0 x 4
 };

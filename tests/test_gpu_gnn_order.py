@@ -97,7 +97,7 @@ def test_streaming_kernel_on_the_other_regular_degrees(name, B):
     from feedback_gnn_amd.graph import GnnWeights
     from feedback_gnn_amd.weights_io import read_weight_list
     og, gg = oracle_library_forms(name), gpu_graph(name)
-    assert gg.info()["regular"] and gg.gnn_factored and gg.gnn_stream
+    assert gg.info()["regular"] and gg.gnn_factored == LIBRARY_GNN_FACTORED and gg.gnn_stream
     ex, ez = og.pauli_noise(SEED, 0.06, 3, B)
     sx, sz = og.syndrome(ex, ez)
     o = og.bp4_decode(sx, sz, 12, "boxplus-phi", 1.0, llr_const=llr_const(0.05))

@@ -9,8 +9,10 @@ entry whose sources differ from the tree's.
 
     python tools/make_traffic_json.py <tag> sandwich:ghp882:65536:64=<summary> sandwich:ghp1270:32768:64=<summary> \
                                             gnnbp4:ghp1270:16384:10=<summary> > profiles/traffic.json
-A `merge=<traffic.json>` argument keeps the entries of an existing file that this call does not re-measure (a refresh of one
-configuration after only its kernel changed).
+A spec is kind:code:B:iters[:cn_type[:forms]]; forms = "literal" (default: the library's default operation sequence, keys without a
+suffix) or "reassociated" (the opt-in forms: keys get `_shared` (bp4) / `_factored` (gnn, gnnbp4), as bench.pmc_key names them).
+A `merge=<traffic.json>` argument keeps the entries of an existing file that this call does not re-measure and that were measured on
+the current kernel sources (a refresh of one configuration after only its kernel changed); stale entries are dropped.
 """
 import json
 import os
@@ -73,28 +75,42 @@ out = {}
 for spec in sys.argv[2:]:
     what, path = spec.split("=", 1)
     if what == "merge":
-        out.update(json.load(open(path)))
+        # keep what this call does not re-measure — but only entries measured on the CURRENT kernel sources: bench.py refuses any other
+        # (pmc_entry), so a stale entry is dead weight that reads like evidence
+        for k, e in json.load(open(path)).items():
+            if e.get("csrc_sha256") == _lib.source_fingerprint(k.split("_")[0]):
+                out[k] = e
         continue
-    kind, code, B, iters, *cn = what.split(":")  # optional fifth field: the check-node rule when it is not 'boxplus-phi' (bench.py's key suffix)
-    suffix = f"_{cn[0]}" if cn and cn[0] != "boxplus-phi" else ""
+    kind, code, B, iters, *rest = what.split(":")  # optional: the check-node rule when it is not 'boxplus-phi', then the forms the pass ran
+    cn = rest[0] if rest and rest[0] else "boxplus-phi"
+    reassoc = len(rest) > 1 and rest[1] == "reassociated"
+    suffix = "" if cn == "boxplus-phi" else f"_{cn}"
     rows = read_rows(path)
     if kind == "sandwich":
         # the FIRST decoder's launch (constant channel LLR: template argument NQ = 0) — the later decoders of a sandwich carry
         # their per-qubit channel LLRs in registers (NQ = 4 / 5) and are a different instantiation
-        # (template tail: ..., NQ, TRACE, GMEM> — GMEM appeared in round 5; the round-4 summaries end in NQ, TRACE>)
-        bp = pick(rows, "bp4_kernel", lambda nm: re.search(r",\s*0,\s*false(,\s*false)?>$", nm) is not None)
+        # (template tail: ..., NQ, TRACE, GMEM, LSE> — LSE appeared in round 6: 0 = literal, 1 = shared log-sum-exp (compile-time forms of
+        # the (3,3,6) phi kernels), 2 = chosen at run time; GMEM in round 5; the round-4 summaries end in NQ, TRACE>)
+        want_lse = ("1", "2") if reassoc else ("0", "2")
+        def is_first_decoder(nm):
+            m = re.search(r",\s*0,\s*false,\s*false,\s*([012])>$", nm)
+            return m is not None and m.group(1) in want_lse
+        bp = pick(rows, "bp4_kernel", is_first_decoder)
         if bp:
             (name, wg), v = bp
-            out[f"bp4_{code}_it{iters}_B{B}{suffix}"] = entry("bp4", name, v)
-        gn = pick(rows, "gnn_stream_kernel") or pick(rows, "gnn_mfma_kernel")  # the streaming VALU kernel is the default of the factored order
+            out[f"bp4_{code}_it{iters}_B{B}{suffix}" + ("_shared" if reassoc else "")] = entry("bp4", name, v)
+        # the streaming VALU kernel runs launches of 4 096 codewords or more (either association: <DV, LITERAL, EMBPK>), the MFMA tiles the rest
+        want_lit = "false" if reassoc else "true"
+        gn = (pick(rows, "gnn_stream_kernel", lambda nm: re.search(r"<\d+,\s*" + want_lit + r",", nm) is not None)
+              or pick(rows, "gnn_mfma_kernel", lambda nm: re.search(r",\s*" + ("true" if reassoc else "false") + r">$", nm) is not None))
         if gn:
             (name, wg), v = gn
-            out[f"gnn_{code}_B{B}"] = entry("gnn", name, v)
+            out[f"gnn_{code}_B{B}" + ("_factored" if reassoc else "")] = entry("gnn", name, v)
     elif kind == "gnnbp4":
         gb = pick(rows, "gnn_bp4")
         if gb:
             (name, wg), v = gb
-            out[f"gnnbp4_{code}_it{iters}_B{B}"] = entry("gnnbp4", name, v)
+            out[f"gnnbp4_{code}_it{iters}_B{B}" + ("_factored" if reassoc else "")] = entry("gnnbp4", name, v)
     else:
         raise SystemExit(f"unknown kind {kind}")
 print(json.dumps(out, indent=1))

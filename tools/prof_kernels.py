@@ -13,10 +13,10 @@ ITERS = [int(x) for x in sys.argv[4].split(',')] if len(sys.argv) > 4 else [64, 
 g = TannerGraph(code(name))
 g.set_saturation_shortcut(len(sys.argv) > 3 and sys.argv[3] == 'product')
 import os
-if os.environ.get("FGNN_BENCH_BP4_LSE"):
-    g.set_bp4_shared_lse(os.environ["FGNN_BENCH_BP4_LSE"] != "literal")
-if os.environ.get("FGNN_BENCH_GNN_ORDER"):  # "literal" / "factored": the same switch as bench.py (default: the library's)
-    g.set_gnn_factored(os.environ["FGNN_BENCH_GNN_ORDER"] != "literal")
+if os.environ.get("FGNN_BENCH_BP4_LSE"):  # "literal" (the library default) / "shared": the same switches as bench.py
+    g.set_bp4_shared_lse(os.environ["FGNN_BENCH_BP4_LSE"] == "shared")
+if os.environ.get("FGNN_BENCH_GNN_ORDER"):  # "literal" (the library default) / "factored"
+    g.set_gnn_factored(os.environ["FGNN_BENCH_GNN_ORDER"] == "factored")
 P = float(sys.argv[5]) if len(sys.argv) > 5 else 0.01
 CN = sys.argv[6] if len(sys.argv) > 6 else "boxplus-phi"
 FACTOR = float(sys.argv[7]) if len(sys.argv) > 7 else 1.0
