@@ -14,19 +14,26 @@ class OSD0_Decoder:
     model's device graph (`fgnn_graph_set_basis`) and only the BP failures are re-solved; the reference's standalone
     ``decoder(llr, pcm, s, bs)`` is served by `__call__` below through the same HIP kernel (`fgnn_osd0`)."""
 
+    MAX_CACHED = 4  # device graphs kept (a script alternates the hx and the hz basis, bp_osd.py:147-157: two)
+
     def __init__(self, n, device=None):
         self.n = int(n)
         self._device = device
-        self._graphs = {}  # basis bytes -> device graph with the basis installed (a caller reuses one basis for every batch)
+        self._graphs = {}  # basis bytes -> device graph with the basis installed (a caller reuses its bases for every batch)
+        self._seen = {}    # identity of a pcm tensor already resolved (storage pointer, shape, strides, version) -> its graph
 
     def _graph_of(self, basis):
         from .decoding import _binary_graph
         key = (basis.shape, basis.tobytes())
-        g = self._graphs.get(key)
+        g = self._graphs.pop(key, None)
         if g is None:
             g = _binary_graph(basis, None, self._device)
             g.set_basis(0, np.arange(basis.shape[0], dtype=np.int32))
-            self._graphs = {key: g}
+        self._graphs[key] = g  # most recently used last
+        while len(self._graphs) > self.MAX_CACHED:
+            old = next(iter(self._graphs))
+            self._seen = {k: v for k, v in self._seen.items() if v is not self._graphs[old]}
+            del self._graphs[old]
         return g
 
     def __call__(self, llr, pcm, s, bs=None):
@@ -34,23 +41,40 @@ class OSD0_Decoder:
         reliable "no error" positions become the pivots), ``pcm [bs, rank, n]`` the FULL-RANK row basis tiled over the batch (the
         reference's models tile one matrix, :147-150; this implementation requires that — or takes a plain ``[rank, n]`` matrix),
         ``s [rank, bs]`` the syndrome of those rows → ``e_hat [bs, n]`` bool with ``pcm e_hat = s`` on the most reliable basis.
-        Ties in the sort keep qubit order (tf.argsort leaves them unspecified)."""
+        Ties in the sort keep qubit order (tf.argsort leaves them unspecified).
+
+        Host-side cost: the first call with a given ``pcm`` tensor checks that it is one matrix tiled over the batch (skipped for an
+        expanded, stride-0 batch dimension), copies it to the host once and builds (or finds) its device graph; later calls with the
+        SAME tensor (same storage, shape, strides and version counter) go straight to the kernel — no device synchronisation, no copy,
+        no hash."""
         pcm_t = torch.as_tensor(pcm)
-        if pcm_t.dim() == 3:
-            if pcm_t.shape[0] > 1 and not bool((pcm_t == pcm_t[:1]).all()):
-                raise NotImplementedError("OSD0_Decoder: one row basis per call (the reference tiles the same matrix over the batch)")
-            pcm_t = pcm_t[0]
-        basis = np.ascontiguousarray(pcm_t.cpu().numpy() != 0, dtype=np.uint8)
-        if basis.shape[1] != self.n:
-            raise ValueError("pcm must have n columns")
-        g = self._graph_of(basis)
+        ident = (pcm_t.untyped_storage().data_ptr(), pcm_t.storage_offset(), tuple(pcm_t.shape), tuple(pcm_t.stride()), pcm_t._version,
+                 pcm_t.dtype, str(pcm_t.device))
+        # only a torch tensor has a version counter that sees in-place writes; anything else (a NumPy array ...) is resolved by content
+        is_tensor = isinstance(pcm, torch.Tensor)
+        g = self._seen.get(ident) if is_tensor else None
+        if g is None:
+            if pcm_t.dim() == 3:
+                tiled = pcm_t.shape[0] <= 1 or pcm_t.stride(0) == 0 or bool((pcm_t == pcm_t[:1]).all())
+                if not tiled:
+                    raise NotImplementedError("OSD0_Decoder: one row basis per call (the reference tiles the same matrix over the batch)")
+                pcm_t = pcm_t[0]
+            basis = np.ascontiguousarray(pcm_t.cpu().numpy() != 0, dtype=np.uint8)
+            if basis.shape[1] != self.n:
+                raise ValueError("pcm must have n columns")
+            g = self._graph_of(basis)
+            if len(self._seen) > 64:
+                self._seen.clear()
+            if is_tensor:
+                self._seen[ident] = g
+        rank = g.m_x
         llr = torch.as_tensor(llr, device=g.device).to(torch.float32).contiguous()
         B = int(llr.shape[0])
         if bs is not None and int(bs) != B:
             raise ValueError("bs must equal the leading dimension of llr")
         synd = (torch.as_tensor(s, device=g.device).to(torch.int64) & 1).to(torch.uint8).t().contiguous()
-        if tuple(synd.shape) != (B, basis.shape[0]):
-            raise ValueError(f"s must have shape [{basis.shape[0]}, {B}]")
+        if tuple(synd.shape) != (B, rank):
+            raise ValueError(f"s must have shape [{rank}, {B}]")
         e_hat = torch.zeros((B, self.n), dtype=torch.uint8, device=g.device)
         g.osd0(0, synd, e_hat, llr_bin=llr)
         return e_hat.bool()

@@ -1087,6 +1087,16 @@ static int bp4_decode_core(const fgnn_graph* g, int cn_type, int num_iter, float
         per = (per + 3) & ~3;
         a.lds_per_cw = per;
         const size_t ws_bytes = (size_t)L.blocks * (size_t)per * sizeof(float);
+        {   // one workspace row per codeword of the launch (254 KB for a [[6480,1296]] code): say so before an allocation of that size
+            // fails as a bare HIP error — the caller decodes in smaller batches
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && ws_bytes > free_b)
+                return fgnn_fail(FGNN_ERR_ARG, "code too large for the LDS-resident kernel: the global-memory variant needs " +
+                                                   std::to_string(ws_bytes >> 20) + " MiB of workspace for " + std::to_string(B) +
+                                                   " codewords (" + std::to_string((size_t)per * sizeof(float) >> 10) + " KiB each) and " +
+                                                   std::to_string(free_b >> 20) + " MiB are free: decode in batches of at most " +
+                                                   std::to_string(free_b / ((size_t)per * sizeof(float) * 2)) + " codewords");
+        }
         void* ws = nullptr;
         FGNN_HIP_CHECK(hipMallocAsync(&ws, ws_bytes, st));
         a.gmem = static_cast<float*>(ws);

@@ -83,7 +83,10 @@ class QLDPCBPDecoder:
     def cal_logit(self, llrx, llry, llrz):
         """Soft syndromes of given marginals (decoding_q.py:455-471): ``llrx, llry, llrz [n, bs]`` (the layout `call` holds them in)
         → ``(x_perp_logit[rows_x, bs], z_perp_logit[rows_z, bs])``.  Evaluated by the decoder kernel's own epilogue: a zero-iteration
-        decode whose channel LLRs are the given marginals returns them unchanged together with their soft syndromes."""
+        decode whose channel LLRs are the given marginals returns them unchanged together with their soft syndromes.  The epilogue
+        (`_cn_update_phi_loss`, :433-453) is the same code for every check-node rule; the call names 'minsum' so that it always runs on
+        the shared float32 routines — bit-equal to the oracle's restatement — even when the opt-in FGNN_OPT_HW_TRANSCENDENTALS is on
+        (that option only ever applies to 'boxplus-phi' launches) and whatever this decoder's own cn_type / normalization factor are."""
         g = self.graph
         llr = torch.stack([torch.as_tensor(t, device=g.device).to(torch.float32) for t in (llrx, llry, llrz)], dim=0)  # [3, n, bs]
         if llr.dim() != 3 or llr.shape[1] != self._num_vns:
@@ -92,7 +95,7 @@ class QLDPCBPDecoder:
         B = llr.shape[0]
         sx = torch.zeros((B, self._num_cns_x), dtype=torch.uint8, device=g.device)
         sz = torch.zeros((B, self._num_cns_z), dtype=torch.uint8, device=g.device)
-        out = g.bp4_decode(sx, sz, 0, self._cn_type, self._normalization_factor, llr_ch=llr, want_logits=True)
+        out = g.bp4_decode(sx, sz, 0, "minsum", 1.0, llr_ch=llr, want_logits=True)
         return out["x_logit"].t(), out["z_logit"].t()
 
     def _syndrome_in(self, s, rows):

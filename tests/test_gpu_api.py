@@ -596,6 +596,22 @@ def test_osd0_decoder_standalone_call(name):
         assert np.array_equal(e[b], _numpy_osd0(llr[b], basis, s[:, b].astype(np.uint8))), b
     e2 = osd.call(llr, basis, s)  # a plain [rank, n] matrix, host inputs, the cached graph
     assert torch.equal(e2, e_hat)
+    # advisor (round 5): the same pcm tensor again goes straight to the kernel (identity cache: no sync, no copy, no hash); an expanded
+    # (stride-0) batch needs no tile check; a second basis does not evict the first (a script alternates hx and hz); an in-place write
+    # to the tensor bumps its version and is seen
+    g1 = osd._seen[next(iter(osd._seen))]
+    assert torch.equal(osd(torch.from_numpy(llr).cuda(), pcm, torch.from_numpy(s).cuda(), B), e_hat) and len(osd._graphs) == 1
+    exp = torch.from_numpy(basis.astype(np.int32)).cuda()[None].expand(B, rank, n)
+    assert torch.equal(osd(torch.from_numpy(llr).cuda(), exp, torch.from_numpy(s).cuda(), B), e_hat) and len(osd._graphs) == 1
+    other = np.asarray(c.hz)[np.asarray(c.pivot_hz)].astype(np.uint8)
+    so = (err.astype(np.int64) @ other.T.astype(np.int64) % 2).astype(np.int64).T
+    eo = osd(llr, torch.from_numpy(other.astype(np.int32)).cuda(), so).cpu().numpy().astype(np.int64)
+    assert np.array_equal(eo @ other.T.astype(np.int64) % 2, so.T) and len(osd._graphs) == 2 and g1 in osd._graphs.values()
+    pcm[:, 0, :] ^= pcm[:, 1, :]  # another basis of the same row space, written in place: resolved afresh, still a valid solution
+    s2 = s.copy()
+    s2[0] ^= s2[1]
+    e3 = osd(torch.from_numpy(llr).cuda(), pcm, torch.from_numpy(s2).cuda(), B).cpu().numpy().astype(np.int64)
+    assert len(osd._graphs) == 3 and np.array_equal(e3 @ basis.T.astype(np.int64) % 2, s.T)
     with pytest.raises(NotImplementedError):
         bad = pcm.clone()
         bad[1, 0, :] ^= 1
@@ -615,6 +631,12 @@ def test_cal_logit_and_the_rest_of_the_decoder_surface():
     llrx, llry, llrz, _, _, x_logit, z_logit = dec.call((llr, torch.from_numpy(sx.T.copy()).cuda(), torch.from_numpy(sz.T.copy()).cuda()))
     xl, zl = dec.cal_logit(llrx.t(), llry.t(), llrz.t())
     assert torch.equal(xl, x_logit) and torch.equal(zl, z_logit) and tuple(xl.shape) == (c.hz.shape[0], B)
+    dec.graph.set_hw_transcendentals(True)  # advisor (round 5): the opt-in hardware path must not reach cal_logit
+    try:
+        xh, zh = dec.cal_logit(llrx.t(), llry.t(), llrz.t())
+    finally:
+        dec.graph.set_hw_transcendentals(False)
+    assert torch.equal(xh, x_logit) and torch.equal(zh, z_logit)
     with pytest.raises(NotImplementedError):
         dec.show_weights()
     b2 = F.LDPCBPDecoder(np.asarray(c.hx), cn_type="minsum", num_iter=7, normalization_factor=0.9, is_syndrome=True, hard_out=True)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Everything profiles/ cites for a round, in phases that each fit one gpurun call (20 minutes):
-#     bash tools/final_profile.sh <tag> tests counts        then        bash tools/final_profile.sh <tag> lines traces
+#     bash tools/final_profile.sh <tag> tests counts   then   COUNT_CONFIGS="c5 n882 ..." bash tools/final_profile.sh <tag> counts   then   ... <tag> lines traces
+# (`counts` measures COUNT_CONFIGS, default "c3 c4 c1 c1phi c3r": four rocprofv3 --pmc passes of 20-40 s per configuration — all thirteen do not fit one call)
 # (GPU tests; the PMC passes of the BASELINE configurations -> traffic.json; the five bench lines; a rocprofv3 kernel trace of the
 # same bench commands; the batch-size table).  Copy what is to be judged from gpurun_out/<tag>/ into profiles/ afterwards.
 set -e
@@ -18,11 +19,12 @@ tail -2 $O/pytest_gpu.log
 fi
 if has counts; then
 # counts first: the bench lines below then quote THIS library's PMC passes (library_is_the_profiled_binary: true)
-bash tools/refresh_traffic.sh $TAG c1 c1phi c3 c4 c5 n882 n1270 q882 q1270 osdms > $O/refresh.log 2>&1
+bash tools/refresh_traffic.sh $TAG ${COUNT_CONFIGS:-c3 c4 c1 c1phi c3r} >> $O/refresh.log 2>&1
 cp $O/traffic.json profiles/traffic.json
+cp profiles/traffic.json $O/traffic_after_counts.json
 fi
 if has lines; then
-python bench.py --no-build --require-roofline > $O/bench_c3.json 2> $O/bench.err
+python bench.py --no-build --steps 20 --warmup 5 --require-roofline > $O/bench_c3.json 2> $O/bench.err   # the driver's own command line
 python bench.py --no-build --config c4 --require-roofline > $O/bench_c4.json 2>> $O/bench.err
 python bench.py --no-build --config c5 --require-roofline > $O/bench_c5.json 2>> $O/bench.err
 # configs[0] as the reference constructs it (cn_type='boxplus', normalization_factor=0.625) and the QLDPC.ipynb cell 11 variant ('boxplus-phi')
