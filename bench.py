@@ -648,14 +648,14 @@ def sandwich_roofline(code_name, dims, launches, launches_per_step, B, iters, fa
 
 
 def gnnbp4_forms_agreement(g, wdev, sx, sz, num_iter, workspace):
-    """GNN_BP4 on the same syndromes under the factored (default) and the literal association, compared per sample.
+    """GNN_BP4 on the same syndromes under the opt-in factored and the literal (default) association, compared per sample.
     make_hard_decision = argmin over (0, X, Z, Y) (gnn.py:359-367): a qubit whose two smallest candidates are closer than twice the
     LLR tolerance may legitimately decide either way under a 1e-6 perturbation — with untrained (seeded) weights the marginals of
     many qubits sit that close to the boundary.  A differing decision BEYOND the tolerance would be a defect."""
     import torch
     prev = g.gnn_factored
     res = []
-    for f in (prev, False):
+    for f in (True, False):
         g.set_gnn_factored(f)
         res.append(g.gnn_bp4_decode(wdev, sx, sz, num_iter, return_logits=False, workspace=workspace))
     g.set_gnn_factored(prev)
