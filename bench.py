@@ -201,6 +201,24 @@ def pmc_entry(kind, key):
                  f"csrc_sha256 {fp[:12]}); counts are per launch of this shape, not measured in this run")
 
 
+def sharding_report(step_ranges, rank_rows, W, K, world, B, reduced_counts):
+    """The proof a multi-GPU line carries that the batch was sharded as DESIGN.md §6 says (host-only, unit-tested on CPU):
+    `step_ranges[r]` = the K half-open global sample ranges rank r decoded in the timed region, `rank_rows[r]` = [rank, first, last,
+    flagged, block_errors, samples] of that rank BEFORE the all-reduce, `reduced_counts` = the three all-reduced counters.  The world * K
+    ranges must tile [W * world * B, (W + K) * world * B) without gap or overlap, each of length B, and the ranks' own counters must
+    add up to the reduced ones.  Returns (the `dist.sharding` object, ok)."""
+    flat = sorted((int(a), int(b)) for per_rank in step_ranges for a, b in per_rank)
+    lo, hi = W * world * B, (W + K) * world * B
+    tiles = (len(flat) == world * K and flat[0][0] == lo and flat[-1][1] == hi
+             and all(flat[i][1] == flat[i + 1][0] for i in range(len(flat) - 1)) and all(b - a == B for a, b in flat))
+    sums = [sum(int(r[3 + j]) for r in rank_rows) for j in range(3)]
+    adds_up = sums == [int(v) for v in reduced_counts]
+    rep = {"timed_region_samples": [lo, hi], "batches": len(flat), "ranges_tile_the_region_without_overlap": bool(tiles),
+           "sum_of_rank_counts": {"flagged": sums[0], "block_errors": sums[1], "samples": sums[2]},
+           "sum_of_rank_counts_equals_all_reduced": bool(adds_up)}
+    return rep, bool(tiles and adds_up)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1130,16 +1148,7 @@ def main():
             rr = [r for r in rank_rows if r[0] == row["rank"]][0]
             row["timed_samples"] = [int(rr[1]), int(rr[2])]
             row["own_counts"] = {"flagged": int(rr[3]), "block_errors": int(rr[4]), "samples": int(rr[5])}
-        flat = sorted((int(a), int(b)) for per_rank in step_ranges for a, b in per_rank)
-        lo, hi = W * world * B, (W + K) * world * B
-        tiles = (len(flat) == world * K and flat[0][0] == lo and flat[-1][1] == hi
-                 and all(flat[i][1] == flat[i + 1][0] for i in range(len(flat) - 1)) and all(b - a == B for a, b in flat))
-        sums = [sum(int(r[3 + j]) for r in rank_rows) for j in range(3)]
-        out["dist"]["sharding"] = {"timed_region_samples": [lo, hi], "batches": len(flat),
-                                   "ranges_tile_the_region_without_overlap": bool(tiles),
-                                   "sum_of_rank_counts": {"flagged": sums[0], "block_errors": sums[1], "samples": sums[2]},
-                                   "sum_of_rank_counts_equals_all_reduced": sums == [int(cnt[0]), int(cnt[1]), int(cnt[2])]}
-        sharding_ok = tiles and sums == [int(cnt[0]), int(cnt[1]), int(cnt[2])]
+        out["dist"]["sharding"], sharding_ok = sharding_report(step_ranges, rank_rows, W, K, world, B, cnt)
 
     fa = None
     if rank == 0 and world == 1 and not args.no_literal:

@@ -96,9 +96,10 @@ og_graph* og_graph_create(int n, int m_x, int m_z, int E_x, const int32_t* chk_x
                           const int32_t* chk_z, const int32_t* var_z)
 {
     og_graph* g = (og_graph*)calloc(1, sizeof(og_graph));
-    /* A graph starts as the LITERAL restatement of the reference (one Dense per edge, one log-sum-exp per edge).  The two
-     * re-associations libfgnn_hip runs by default (FGNN_OPT_GNN_FACTORED, FGNN_OPT_BP4_SHARED_LSE) are restated next to it and a
-     * checker asks for them explicitly: og_graph_set_gnn_order(g, 1), og_graph_set_vn_shared_lse(g, 1). */
+    /* A graph starts as the LITERAL restatement of the reference (one Dense per edge, one log-sum-exp per edge) — which is also what
+     * libfgnn_hip runs by default since round 6.  The library's two OPT-IN re-associations (FGNN_OPT_GNN_FACTORED,
+     * FGNN_OPT_BP4_SHARED_LSE) are restated next to it and a checker asks for them explicitly: og_graph_set_gnn_order(g, 1),
+     * og_graph_set_vn_shared_lse(g, 1). */
     g->gnn_order = 0;
     g->vn_shared_lse = 0;
     g->n = n;

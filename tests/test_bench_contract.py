@@ -301,6 +301,42 @@ def test_roofline_counts_are_fingerprinted_and_the_fraction_is_a_fraction():
     assert e["hbm_bytes_per_launch"] / (e["avg_ms_under_pmc"] * 1e-3) / 1e9 / bench.HBM_PEAK_GBS < 0.05
 
 
+def test_sharding_report_accepts_the_partition_and_names_every_way_it_can_fail():
+    """bench.sharding_report (the `dist.sharding` object of a multi-GPU line; rank 0 exits 8 when it is not ok): rank r of `world`
+    decodes block r of every `world` consecutive blocks of B samples (Sandwich_BP_GNN_Evaluation_Model._take_samples) — W warm-up
+    steps, then K timed ones.  Eight ranks as the first SCALE run will have them; then a gap, an overlap, a rank off by one block, a
+    short batch, a missing rank and counters that do not add up."""
+    import bench
+    W, K, world, B = 5, 20, 8, 65536
+    ranges = [[[(W + k) * world * B + r * B, (W + k) * world * B + (r + 1) * B] for k in range(K)] for r in range(world)]
+    rows = [[r, ranges[r][0][0], ranges[r][-1][1], 3 + r, 2 + r, K * B] for r in range(world)]
+    total = [sum(x[3] for x in rows), sum(x[4] for x in rows), world * K * B]
+    rep, ok = bench.sharding_report(ranges, rows, W, K, world, B, total)
+    assert ok and rep["ranges_tile_the_region_without_overlap"] and rep["sum_of_rank_counts_equals_all_reduced"]
+    assert rep["timed_region_samples"] == [W * world * B, (W + K) * world * B] and rep["batches"] == world * K
+    assert rep["sum_of_rank_counts"] == {"flagged": total[0], "block_errors": total[1], "samples": total[2]}
+    import copy
+    def broken(edit, counts=total, rws=rows):
+        rg = copy.deepcopy(ranges)
+        edit(rg)
+        return bench.sharding_report(rg, rws, W, K, world, B, counts)
+    rep, ok = broken(lambda rg: rg[3].__setitem__(7, [rg[3][7][0] + B, rg[3][7][1] + B]))        # rank 3 decodes rank 4's block once: overlap + gap
+    assert not ok and not rep["ranges_tile_the_region_without_overlap"] and rep["sum_of_rank_counts_equals_all_reduced"]
+    rep, ok = broken(lambda rg: [r.__setitem__(0, [r[0][0] - world * B, r[0][1] - world * B]) for r in rg])  # everybody starts one step early
+    assert not ok and not rep["ranges_tile_the_region_without_overlap"]
+    rep, ok = broken(lambda rg: rg[0].__setitem__(0, [rg[0][0][0], rg[0][0][1] - 1]))              # a short batch
+    assert not ok
+    rep, ok = broken(lambda rg: rg.pop())                                                          # a rank is missing
+    assert not ok and rep["batches"] == (world - 1) * K
+    rep, ok = broken(lambda rg: rg.__setitem__(1, copy.deepcopy(rg[0])))                          # two ranks on the same samples
+    assert not ok and not rep["ranges_tile_the_region_without_overlap"]
+    rep, ok = broken(lambda rg: None, counts=[total[0] + 1, total[1], total[2]])                  # a counter lost or double-counted in the reduction
+    assert not ok and rep["ranges_tile_the_region_without_overlap"] and not rep["sum_of_rank_counts_equals_all_reduced"]
+    # one process is the world-1 case of the same rule
+    rep, ok = bench.sharding_report([[[2048, 4096], [4096, 6144]]], [[0, 2048, 6144, 1, 1, 4096]], 1, 2, 1, 2048, [1, 1, 4096])
+    assert ok and rep["batches"] == 2
+
+
 def test_gnn_flops_are_the_survey_figures():
     """13.4 MFLOP ([[882,24]]) / 19.3 MFLOP ([[1270,28]]) per feedback-GNN pass and codeword."""
     import bench
