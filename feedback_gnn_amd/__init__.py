@@ -22,7 +22,7 @@ def __getattr__(name):
         from . import feedback_gnn as _f
         return getattr(_f, name)
     if name in ("sim_ber", "count_block_errors", "PlotBER", "allreduce_counts", "shard_range", "pack_decisions",
-                "unpack_decisions", "gather_packed", "gather_decisions"):
+                "unpack_decisions", "gather_packed", "gather_decisions", "broadcast_weights"):
         from . import utils as _u
         return getattr(_u, name)
     if name in ("LDPCBPDecoder", "BP_BSC_Model"):

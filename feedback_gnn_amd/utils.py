@@ -105,6 +105,40 @@ def gather_decisions(x_hat, z_hat):
     return unpack_decisions(gather_packed(pack_decisions(x_hat, z_hat)), n)
 
 
+def broadcast_weights(system, src=0, device=None):
+    """One set of weights on every rank: rank ``src``'s ``system.get_weights()`` (a list of float32 arrays, the Keras order of
+    `Feedback_GNN` / `GNN_BP4`) is sent to all ranks with ONE `torch.distributed.broadcast` of the concatenated parameters (3 923
+    floats = 15.7 KB for the shipped feedback GNN; RCCL over xGMI with the nccl backend, through host memory with gloo) and installed
+    with ``system.set_weights``.  The reference evaluates one process per GPU, each loading the same pickle (n882.py:9-25, :52); here a
+    job whose rank 0 alone holds the weights — just trained (`training.py`), or read from a path only it can see — ships them instead.
+    Every rank must have constructed ``system`` with the same architecture: the array shapes come from its own ``get_weights()`` and
+    the total size is checked across ranks before anything is overwritten.  No-op without an initialised process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return system
+    mine = [np.ascontiguousarray(w, dtype=np.float32) for w in system.get_weights()]
+    shapes = [w.shape for w in mine]
+    total = int(sum(w.size for w in mine))
+    nccl = dist.get_backend() == "nccl"
+    dev = (torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)) if nccl else torch.device("cpu")
+    # every rank's parameter count against the source's, before a single weight is touched
+    counts = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, torch.tensor([total], dtype=torch.int64, device=dev))
+    counts = [int(v) for v in counts.cpu()]
+    if any(c != counts[src] for c in counts):
+        raise ValueError(f"broadcast_weights: the ranks hold different architectures (parameter counts {counts})")
+    flat = torch.from_numpy(np.concatenate([w.ravel() for w in mine]) if mine else np.zeros(0, np.float32)).to(dev)
+    dist.broadcast(flat, src=src)
+    flat = flat.cpu().numpy()
+    out, at = [], 0
+    for shp in shapes:
+        k = int(np.prod(shp))
+        out.append(flat[at:at + k].reshape(shp).copy())
+        at += k
+    system.set_weights(out)
+    return system
+
+
 def shard_range(total, rank, world_size):
     """Contiguous slice [lo, hi) of ``total`` samples owned by ``rank`` (sizes differ by at most 1)."""
     base, rem = divmod(int(total), int(world_size))

@@ -80,3 +80,28 @@ def test_nccl_gather_decisions_on_device(nccl_group):
     assert all_packed.is_cuda and torch.equal(all_packed, packed)
     xa, za = gather_decisions(ex, ez)
     assert torch.equal(xa, ex) and torch.equal(za, ez)
+
+
+def test_nccl_broadcast_weights_on_device(nccl_group):
+    """`broadcast_weights` (north star: "RCCL broadcast"): the feedback GNN's 3 923 parameters as ONE broadcast of a device tensor on
+    the nccl group; at world size 1 the collective still runs (not short-circuited) and the weights — host copy and device tables —
+    are what they were, so the decoder's output is unchanged bit for bit."""
+    import feedback_gnn_amd as F
+    from feedback_gnn_amd.utils import broadcast_weights
+    from helpers import WEIGHTS_882, code, llr_const
+    c = code("ghp882")
+    dec = F.QLDPCBPDecoder(code=c, num_iter=8, normalization_factor=1.0, cn_type="boxplus-phi", stage_one=True)
+    G = F.Feedback_GNN(code=c, num_msg_dims=20, num_hidden_units=40, num_mlp_layers=2, reduce_op="mean", activation="tanh", use_bias=True,
+                       graph=dec.graph)
+    F.load_weights(G, WEIGHTS_882)
+    g = dec.graph
+    ex, ez = g.pauli_noise(0x5EED, 0.1, 0, 64)
+    sx, sz = g.syndrome(ex, ez)
+    o = g.bp4_decode(sx, sz, 8, "boxplus-phi", 1.0, llr_const=llr_const(0.05))
+    before = g.feedback_gnn(G.device_weights, o["llr"], o["z_logit"], o["x_logit"], sx, sz).clone()
+    w0 = [w.copy() for w in G.get_weights()]
+    assert broadcast_weights(G, src=0) is G
+    torch.cuda.synchronize()
+    assert all(np.array_equal(a, b) for a, b in zip(w0, G.get_weights())) and G.count_params() == 3923
+    after = g.feedback_gnn(G.device_weights, o["llr"], o["z_logit"], o["x_logit"], sx, sz)
+    assert torch.equal(before, after)
